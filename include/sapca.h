@@ -1,0 +1,239 @@
+/*
+ * sapca.h -- C ABI of the MI355X-native sparse-PCA hot path (libsapca.so).
+ *
+ * Drop-in boundary for single-algebra's src/dimred/pca (reference v0.9.2).  The
+ * reference has no FFI of its own: its boundary is the Rust generic API
+ * (SparsePCABuilder / MaskedSparsePCABuilder / fit / transform / fit_transform)
+ * and, one level down, the single-svdlib calls it makes.  Every entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * repository root); INTEGRATION.md shows the Rust `extern "C"` binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch/HIP types in signatures
+ *     (a HIP stream is passed as void*).
+ *   - every function returns a sapca_status; nothing throws or aborts across the
+ *     ABI.  sapca_last_error(h) gives the message (the reference's anyhow text
+ *     where one exists).
+ *   - _f32/_f64 pairs mirror the reference's generic T (f32/f64 in practice).
+ *   - host CSR inputs use nalgebra_sparse::CsrMatrix's own layout: row_offsets
+ *     and col_indices are usize (uint64_t), zero-copy from Rust.
+ *   - "device" entry points take HBM-resident CSR (int64 row offsets, int32 column
+ *     indices) and device output buffers; they are what bench.py times.
+ *   - inputs are borrowed for the duration of a call; outputs are written into
+ *     caller-allocated buffers.
+ *   - a handle is not thread-safe; distinct handles may be used concurrently.
+ */
+#ifndef SAPCA_H
+#define SAPCA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAPCA_ABI_VERSION 1
+
+typedef struct sapca_handle_s* sapca_handle;
+
+typedef enum sapca_status {
+  SAPCA_OK = 0,
+  SAPCA_ERR_ARG = 1,        /* bad argument / unsupported size                                  */
+  SAPCA_ERR_MASK_LEN = 2,   /* "The mask vector length and the number of features (columns)
+                               have to be the same!"   sparse_masked/mod.rs:258-262, 440-444    */
+  SAPCA_ERR_NOT_FITTED = 3, /* "Must be fitted before transform!" sparse/mod.rs:259,263;
+                               "Model must be fitted first!"      sparse/mod.rs:299,316          */
+  SAPCA_ERR_SVD = 4,        /* "SVD computation failed: .." / "Randomized SVD computation
+                               failed: .." sparse/mod.rs:144,180; also returned where the
+                               reference would panic on s[i] (rank < k), sparse/mod.rs:213-215   */
+  SAPCA_ERR_HIP = 5,        /* HIP runtime error (message carries hipGetErrorString)            */
+  SAPCA_ERR_COMM = 6,       /* RCCL / collective error                                          */
+  SAPCA_ERR_NOMEM = 7
+} sapca_status;
+
+/* SVDMethod                                     src/dimred/pca/mod.rs:49-68 (default Lanczos) */
+typedef enum sapca_method { SAPCA_LANCZOS = 0, SAPCA_RANDOM = 1 } sapca_method;
+/* PowerIterationNormalizer (re-export)          src/dimred/pca/mod.rs:41                      */
+typedef enum sapca_normalizer { SAPCA_NORM_QR = 0, SAPCA_NORM_LU = 1, SAPCA_NORM_NONE = 2 } sapca_normalizer;
+/* transform semantics: REFERENCE reproduces quirks Q2/Q3; CENTERED is the
+ * mathematically centred projection (A - 1 mu^T) V^T, offered as an opt-in superset.          */
+typedef enum sapca_transform_semantics { SAPCA_TRANSFORM_REFERENCE = 0, SAPCA_TRANSFORM_CENTERED = 1 } sapca_transform_semantics;
+
+/* Builder fields.  SparsePCABuilder sparse/mod.rs:375-484 (defaults :392-401);
+ * MaskedSparsePCABuilder sparse_masked/mod.rs:37-160 (defaults :55-66).
+ * alpha and tolerance are stored and never read by the reference; kept for drop-in.          */
+typedef struct sapca_options {
+  uint32_t struct_size;          /* = sizeof(sapca_options); ABI growth guard                   */
+  uint32_t random_seed;          /* .random_seed(u32), default 42                               */
+  uint64_t n_components;         /* .n_components(usize), default 50                            */
+  double alpha;                  /* .alpha(T), default 1.0 (unused)                             */
+  double tolerance;              /* .tolerance(T), default 1e-6 (unused)                        */
+  uint8_t center;                /* .center(bool), default 1                                    */
+  uint8_t verbose;               /* .verbose(bool), default 0                                   */
+  uint8_t collect_timings;       /* record per-stage HIP-event timings (sapca_get_timings)      */
+  uint8_t reserved0;
+  int32_t method;                /* sapca_method, default SAPCA_LANCZOS                         */
+  uint64_t n_oversamples;        /* SVDMethod::Random.n_oversamples                             */
+  uint64_t n_power_iterations;   /* SVDMethod::Random.n_power_iterations                        */
+  int32_t normalizer;            /* sapca_normalizer                                            */
+  int32_t transform_semantics;   /* sapca_transform_semantics                                   */
+  int32_t device_id;             /* HIP device ordinal; -1 = current device                     */
+  int32_t spmm_variant;          /* 0 = auto; 1 = L2-gather row kernel; 2 = LDS-tiled kernel    */
+  void* stream;                  /* hipStream_t to run on; NULL = library-owned stream          */
+} sapca_options;
+
+/* per-stage device timings of the last fit/transform (ms, HIP events on the handle's stream) */
+typedef struct sapca_timings {
+  double upload_ms;          /* narrowing + H2D (host entry points only)                        */
+  double prepare_ms;         /* mask compaction, transpose, tile formats                        */
+  double stats_ms;           /* column statistics                                               */
+  double spmm_ms;            /* sum over the A*X sweeps                                         */
+  double spmmt_ms;           /* sum over the A^T*Y sweeps                                       */
+  double ortho_ms;           /* Gram / Cholesky / panel GEMM                                    */
+  double small_svd_ms;       /* final factorisation incl. host Jacobi                           */
+  double lanczos_ms;
+  double transform_ms;
+  double comm_ms;            /* host-observed time in collectives                               */
+  double fit_total_ms;
+  uint32_t n_spmm;           /* number of A*X sweeps timed                                      */
+  uint32_t n_spmmt;
+  double spmm_sweep_ms[32];  /* individual sweeps, in launch order                              */
+  double spmmt_sweep_ms[32];
+  double bytes_per_sweep;    /* ALGORITHMIC bytes of one sweep (SURVEY.md §8d formula)          */
+  uint64_t lanczos_steps;
+} sapca_timings;
+
+void sapca_options_default(sapca_options* o);
+int sapca_abi_version(void);
+
+/* SparsePCABuilder::build / MaskedSparsePCABuilder::build   sparse/mod.rs:470-483, masked :144-159 */
+sapca_status sapca_create(const sapca_options* opts, sapca_handle* out);
+void sapca_destroy(sapca_handle h);
+const char* sapca_last_error(sapca_handle h);   /* valid until the next call on h; h may be NULL (create errors) */
+
+/* MaskedSparsePCABuilder::mask(Vec<bool>)       sparse_masked/mod.rs:111-114.  len is checked
+ * against ncols at fit/transform time like the reference (:258-262).  len == 0 clears it.    */
+sapca_status sapca_set_mask(sapca_handle h, const uint8_t* mask, size_t len);
+
+/* Test hook: inject the Gaussian test matrix Omega (n_used x (k+p), row-major, host) used by
+ * the next randomized fit instead of the built-in generator -- the reference's rand-0.9
+ * stream is not reproducible, so parity is checked with a shared Omega.       */
+sapca_status sapca_set_omega_f32(sapca_handle h, const float* omega, size_t rows, size_t cols);
+sapca_status sapca_set_omega_f64(sapca_handle h, const double* omega, size_t rows, size_t cols);
+
+/* SparsePCA::fit / MaskedSparsePCA::fit          sparse/mod.rs:102-242; masked :255-419        */
+sapca_status sapca_fit_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                               const uint64_t* row_offsets, const uint64_t* col_indices, const float* values);
+sapca_status sapca_fit_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                               const uint64_t* row_offsets, const uint64_t* col_indices, const double* values);
+/* SparsePCA::transform / MaskedSparsePCA::transform   sparse/mod.rs:255-285; masked :438-546.
+ * out: m x n_components, row-major (ndarray Array2 standard layout).                          */
+sapca_status sapca_transform_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                     const uint64_t* row_offsets, const uint64_t* col_indices, const float* values, float* out);
+sapca_status sapca_transform_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                     const uint64_t* row_offsets, const uint64_t* col_indices, const double* values, double* out);
+/* fit_transform                                   sparse/mod.rs:355-358; masked :616-619        */
+sapca_status sapca_fit_transform_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                         const uint64_t* row_offsets, const uint64_t* col_indices, const float* values, float* out);
+sapca_status sapca_fit_transform_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                         const uint64_t* row_offsets, const uint64_t* col_indices, const double* values, double* out);
+
+/* Same three operations on HBM-resident CSR (device pointers: int64 row offsets [m+1],
+ * int32 column indices [nnz], values [nnz]); `out` is a device buffer m x n_components.
+ * The matrix is borrowed: it must stay valid and unmodified until the call returns.
+ * When the handle belongs to a multi-rank communicator (sapca_comm_*), (m, row_offsets, ..)
+ * describe THIS rank's row shard and n is the global column count.                            */
+sapca_status sapca_fit_csr_device_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                      const int64_t* d_row_offsets, const int32_t* d_col_indices, const float* d_values);
+sapca_status sapca_fit_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                      const int64_t* d_row_offsets, const int32_t* d_col_indices, const double* d_values);
+sapca_status sapca_transform_csr_device_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                            const int64_t* d_row_offsets, const int32_t* d_col_indices, const float* d_values, float* d_out);
+sapca_status sapca_transform_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                            const int64_t* d_row_offsets, const int32_t* d_col_indices, const double* d_values, double* d_out);
+sapca_status sapca_fit_transform_csr_device_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                                const int64_t* d_row_offsets, const int32_t* d_col_indices, const float* d_values, float* d_out);
+sapca_status sapca_fit_transform_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                                const int64_t* d_row_offsets, const int32_t* d_col_indices, const double* d_values, double* d_out);
+
+/* Fitted state.  The reference keeps components_/explained_variance_/mean_ private
+ * (sparse/mod.rs:41-43); a Rust wrapper needs them to populate those fields.
+ * dims: k = n_components, n_used = columns seen by the SVD (n, or n' under a mask),
+ * n_cols = columns of the fitted matrix (length of mean_).                                    */
+sapca_status sapca_get_dims(sapca_handle h, uint64_t* k, uint64_t* n_used, uint64_t* n_cols);
+sapca_status sapca_get_components_f32(sapca_handle h, float* out, size_t cap);            /* k x n_used   sparse/mod.rs:208 */
+sapca_status sapca_get_components_f64(sapca_handle h, double* out, size_t cap);
+sapca_status sapca_get_singular_values_f32(sapca_handle h, float* out, size_t cap);       /* k            res.s             */
+sapca_status sapca_get_singular_values_f64(sapca_handle h, double* out, size_t cap);
+sapca_status sapca_get_explained_variance_f32(sapca_handle h, float* out, size_t cap);    /* k            sparse/mod.rs:210-216 */
+sapca_status sapca_get_explained_variance_f64(sapca_handle h, double* out, size_t cap);
+sapca_status sapca_get_mean_f32(sapca_handle h, float* out, size_t cap);                  /* n_cols       sparse/mod.rs:106-117 */
+sapca_status sapca_get_mean_f64(sapca_handle h, double* out, size_t cap);
+sapca_status sapca_get_total_variance(sapca_handle h, double* out);                       /* sparse/mod.rs:119-131, 218-223 */
+/* explained_variance_ratio()                      sparse/mod.rs:312-322; masked :574-582       */
+sapca_status sapca_get_explained_variance_ratio_f32(sapca_handle h, float* out, size_t cap);
+sapca_status sapca_get_explained_variance_ratio_f64(sapca_handle h, double* out, size_t cap);
+/* cumulative_explained_variance_ratio()           sparse/mod.rs:333-343; masked :593-603       */
+sapca_status sapca_get_cumulative_explained_variance_ratio_f32(sapca_handle h, float* out, size_t cap);
+sapca_status sapca_get_cumulative_explained_variance_ratio_f64(sapca_handle h, double* out, size_t cap);
+/* feature_importances()                           sparse/mod.rs:295-302; masked :557-564       */
+sapca_status sapca_get_feature_importances_f32(sapca_handle h, float* out, size_t cap);   /* k x n_used */
+sapca_status sapca_get_feature_importances_f64(sapca_handle h, double* out, size_t cap);
+/* cols_to_use (ascending, sparse_masked/mod.rs:264-271) and the col -> masked-index map of
+ * :462-466 as a dense table (-1 = column dropped).  Integer, bit-exact.  Either may be NULL.  */
+sapca_status sapca_get_mask_index_maps(sapca_handle h, uint64_t* cols_to_use, size_t cap_cols,
+                                       int64_t* orig_to_masked, size_t cap_map);
+sapca_status sapca_get_timings(sapca_handle h, sapca_timings* out);
+
+/* ---- stage-level operators (host buffers in and out), used by the parity tests ------------ */
+/* <CsrMatrix as MatrixSum>::sum_col / sum_col_squared   src/sparse/csr.rs:259-312, 558-608.
+ * One fused device pass yields both plus the per-column stored-entry count (any may be NULL). */
+sapca_status sapca_colstats_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                    const uint64_t* row_offsets, const uint64_t* col_indices, const float* values,
+                                    float* sum_col, float* sum_col_squared, uint64_t* nonzero_col);
+sapca_status sapca_colstats_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                    const uint64_t* row_offsets, const uint64_t* col_indices, const double* values,
+                                    double* sum_col, double* sum_col_squared, uint64_t* nonzero_col);
+/* The two sweeps inside single_svdlib::randomized::randomized_svd (call sites
+ * sparse/mod.rs:170-180): Y = (A - 1 mu^T) X   (X: n x l, Y: m x l) and
+ * Z = (A - 1 mu^T)^T Y (Y: m x l, Z: n x l); row-major, mu may be NULL (uncentred).         */
+sapca_status sapca_spmm_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                const uint64_t* row_offsets, const uint64_t* col_indices, const float* values,
+                                const float* mu, uint64_t l, const float* X, float* Y);
+sapca_status sapca_spmm_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                const uint64_t* row_offsets, const uint64_t* col_indices, const double* values,
+                                const double* mu, uint64_t l, const double* X, double* Y);
+sapca_status sapca_spmmt_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                 const uint64_t* row_offsets, const uint64_t* col_indices, const float* values,
+                                 const float* mu, uint64_t l, const float* Y, float* Z);
+sapca_status sapca_spmmt_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                 const uint64_t* row_offsets, const uint64_t* col_indices, const double* values,
+                                 const double* mu, uint64_t l, const double* Y, double* Z);
+/* PowerIterationNormalizer applied to a rows x l row-major panel in place (QR: orthonormal
+ * basis of the same span; LU: well-conditioned basis of the same span; NONE: untouched).     */
+sapca_status sapca_normalize_panel_f32(sapca_handle h, int32_t normalizer, uint64_t rows, uint64_t l, float* panel);
+sapca_status sapca_normalize_panel_f64(sapca_handle h, int32_t normalizer, uint64_t rows, uint64_t l, double* panel);
+/* The built-in Omega generator (rows x l standard normal from (seed)), for inspection.        */
+sapca_status sapca_generate_omega_f32(sapca_handle h, uint64_t rows, uint64_t l, float* out);
+sapca_status sapca_generate_omega_f64(sapca_handle h, uint64_t rows, uint64_t l, double* out);
+
+/* ---- multi-GPU: one process per GPU, rows range-partitioned ---------------- */
+/* nnz-balanced contiguous row ranges: bounds[0]=0 <= ... <= bounds[nparts]=m.  Pure host code. */
+sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint32_t nparts, uint64_t* bounds);
+/* Built-in collective = RCCL (resolved at run time from librccl.so.1).  Rank 0 creates the
+ * 128-byte id and the host program distributes it (torch.distributed broadcast, MPI, a file).  */
+sapca_status sapca_comm_unique_id(uint8_t id[128]);
+sapca_status sapca_comm_init_rank(sapca_handle h, uint32_t nranks, uint32_t rank, const uint8_t id[128]);
+/* Or bring your own all-reduce(sum) over all ranks: `buf` is a DEVICE pointer holding `count`
+ * elements of dtype (0 = f32, 1 = f64), reduced in place, ordered on `stream` (hipStream_t).
+ * Return 0 on success.                                                                        */
+typedef int (*sapca_allreduce_fn)(void* ctx, void* buf, uint64_t count, int32_t dtype, void* stream);
+sapca_status sapca_comm_set_callback(sapca_handle h, uint32_t nranks, uint32_t rank, sapca_allreduce_fn fn, void* ctx);
+/* Invokes the handle's collective once on a caller buffer (plumbing self-test).               */
+sapca_status sapca_comm_allreduce(sapca_handle h, void* buf, uint64_t count, int32_t dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAPCA_H */

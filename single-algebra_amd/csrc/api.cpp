@@ -1,0 +1,536 @@
+// extern "C" surface of libsapca.so (include/sapca.h).  Every function: set device, try,
+// translate exceptions into a status + per-handle message.  No compute lives here.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "engine.h"
+
+using sapca::CsrView;
+using sapca::Engine;
+using sapca::Error;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename F>
+sapca_status guarded(sapca_handle h, F&& f) {
+  if (!h) return SAPCA_ERR_ARG;
+  try {
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) throw Error(SAPCA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    f();
+    h->err.clear();
+    return SAPCA_OK;
+  } catch (const Error& e) {
+    h->err = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    h->err = "out of host memory";
+    return SAPCA_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return SAPCA_ERR_ARG;
+  }
+}
+
+// Host CSR (nalgebra layout, usize indices) -> device CSR in the handle's upload buffers.
+template <typename T>
+CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* row_offsets,
+                  const uint64_t* col_indices, const T* values) {
+  SAPCA_CHECK(row_offsets != nullptr && (nnz == 0 || (col_indices && values)), SAPCA_ERR_ARG, "null CSR array");
+  SAPCA_CHECK(row_offsets[0] == 0 && row_offsets[m] == nnz, SAPCA_ERR_ARG, "row_offsets do not span [0, nnz]");
+  SAPCA_CHECK(n < (1ull << 31) && m < (1ull << 31), SAPCA_ERR_ARG, "more than 2^31-1 rows or columns is not supported");
+  hipStream_t s = h->stream;
+  h->prep_key.valid = false;  // the upload buffers are about to hold a different matrix
+  const int ev = h->timer.enabled ? -1 : -1;
+  (void)ev;
+  auto t0 = std::chrono::steady_clock::now();
+  int64_t* d_ptr = h->in_ptr.as<int64_t>(m + 1);
+  int32_t* d_idx = h->in_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
+  T* d_val = h->in_val.as<T>(std::max<uint64_t>(nnz, 1));
+  uint64_t* d64 = h->up64.as<uint64_t>(m + 1 + nnz + 8);
+  int* flag = reinterpret_cast<int*>(d64 + m + 1 + nnz);
+  SAPCA_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+  SAPCA_HIP(hipMemcpyAsync(d64, row_offsets, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  if (nnz) {
+    SAPCA_HIP(hipMemcpyAsync(d64 + m + 1, col_indices, nnz * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    SAPCA_HIP(hipMemcpyAsync(d_val, values, nnz * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  sapca::k::narrow_indices(d64, d64 + m + 1, (int64_t)m, (int64_t)nnz, (int64_t)n, d_ptr, d_idx, flag, s);
+  int bad = 0;
+  SAPCA_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  SAPCA_HIP(hipStreamSynchronize(s));
+  SAPCA_CHECK(bad == 0, SAPCA_ERR_ARG, "column index out of range");
+  h->timings.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  CsrView<T> v;
+  v.rows = (int64_t)m; v.cols = (int64_t)n; v.nnz = (int64_t)nnz;
+  v.ptr = d_ptr; v.idx = d_idx; v.val = d_val;
+  return v;
+}
+
+template <typename T>
+CsrView<T> device_view(uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, const int32_t* i, const T* v) {
+  SAPCA_CHECK(p != nullptr && (nnz == 0 || (i && v)), SAPCA_ERR_ARG, "null CSR array");
+  SAPCA_CHECK(n < (1ull << 31) && m < (1ull << 31), SAPCA_ERR_ARG, "more than 2^31-1 rows or columns is not supported");
+  CsrView<T> a;
+  a.rows = (int64_t)m; a.cols = (int64_t)n; a.nnz = (int64_t)nnz; a.ptr = p; a.idx = i; a.val = v;
+  return a;
+}
+
+template <typename T>
+void download_out(sapca_handle h, const T* d, T* out, size_t count) {
+  SAPCA_HIP(hipMemcpyAsync(out, d, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  SAPCA_HIP(hipStreamSynchronize(h->stream));
+}
+
+template <typename T>
+sapca_status fit_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci,
+                      const T* v) {
+  return guarded(h, [&] { Engine<T>::fit(*h, upload<T>(h, m, n, nnz, ro, ci, v)); });
+}
+
+template <typename T>
+sapca_status transform_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,
+                            const uint64_t* ci, const T* v, T* out, bool fit_first) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(out != nullptr || m == 0, SAPCA_ERR_ARG, "null output buffer");
+    if (!fit_first) {
+      if (!h->mask.empty() && h->mask.size() != n)
+        throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
+      if (!h->fitted) throw Error(SAPCA_ERR_NOT_FITTED, "Must be fitted before transform!");
+    }
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    if (fit_first) Engine<T>::fit(*h, A);
+    T* d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * h->k, 1));
+    Engine<T>::transform(*h, A, d_out);
+    download_out(h, d_out, out, (size_t)(m * h->k));
+  });
+}
+
+template <typename T>
+sapca_status fit_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, const int32_t* i,
+                        const T* v) {
+  return guarded(h, [&] { Engine<T>::fit(*h, device_view<T>(m, n, nnz, p, i, v)); });
+}
+
+template <typename T>
+sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p,
+                              const int32_t* i, const T* v, T* d_out, bool fit_first) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(d_out != nullptr || m == 0, SAPCA_ERR_ARG, "null output buffer");
+    CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
+    if (fit_first) Engine<T>::fit(*h, A);
+    Engine<T>::transform(*h, A, d_out);
+  });
+}
+
+template <typename T>
+void copy_out(const std::vector<double>& src, T* out, size_t cap) {
+  SAPCA_CHECK(out != nullptr && cap >= src.size(), SAPCA_ERR_ARG, "output buffer too small");
+  for (size_t i = 0; i < src.size(); ++i) out[i] = (T)src[i];
+}
+
+void need_fitted(sapca_handle h) {
+  if (!h->fitted) throw Error(SAPCA_ERR_NOT_FITTED, "Model must be fitted first!");  // sparse/mod.rs:299,316
+}
+
+// components live on the device in the fitted dtype; fetched (and converted) on demand
+template <typename T>
+void get_components(sapca_handle h, T* out, size_t cap, bool squared) {
+  need_fitted(h);
+  const size_t count = (size_t)(h->k * h->n_used);
+  SAPCA_CHECK(out != nullptr && cap >= count, SAPCA_ERR_ARG, "output buffer too small");
+  if (h->dtype == 0) {
+    std::vector<float> tmp(count);
+    download_out(h, h->components_dev.ptr<float>(), tmp.data(), count);
+    for (size_t i = 0; i < count; ++i) out[i] = squared ? (T)(tmp[i] * tmp[i]) : (T)tmp[i];
+  } else {
+    std::vector<double> tmp(count);
+    download_out(h, h->components_dev.ptr<double>(), tmp.data(), count);
+    for (size_t i = 0; i < count; ++i) out[i] = squared ? (T)(tmp[i] * tmp[i]) : (T)tmp[i];
+  }
+}
+
+template <typename T>
+void get_ratio(sapca_handle h, T* out, size_t cap, bool cumulative) {
+  need_fitted(h);
+  SAPCA_CHECK(out != nullptr && cap >= h->k, SAPCA_ERR_ARG, "output buffer too small");
+  // sparse/mod.rs:318-319: ratio_i = ev_i / sum over the k computed components, in T
+  T total = 0;
+  for (uint64_t i = 0; i < h->k; ++i) total += (T)h->expl_var[i];
+  T run = 0;
+  for (uint64_t i = 0; i < h->k; ++i) {
+    const T r = (T)h->expl_var[i] / total;
+    run += r;  // sparse/mod.rs:336-340
+    out[i] = cumulative ? run : r;
+  }
+}
+
+// stage-level helpers -------------------------------------------------------------------
+template <typename T>
+sapca_status colstats_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,
+                           const uint64_t* ci, const T* v, T* sum_col, T* sum_sq, uint64_t* cnt) {
+  return guarded(h, [&] {
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    hipStream_t s = h->stream;
+    int64_t* at_ptr = h->at_ptr.as<int64_t>(n + 1);
+    int32_t* at_idx = h->at_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
+    T* at_val = h->at_val.as<T>(std::max<uint64_t>(nnz, 1));
+    sapca::k::transpose_csr(A, at_ptr, at_idx, at_val, h->scratch, s);
+    CsrView<T> At;
+    At.rows = (int64_t)n; At.cols = (int64_t)m; At.nnz = (int64_t)nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
+    double* d = h->stats.as<double>(3 * n + 1);
+    sapca::k::row_sums(At, d, d + n, s);
+    sapca::k::row_lengths_f64(at_ptr, (int64_t)n, d + 2 * n, s);
+    std::vector<double> host(3 * n);
+    download_out(h, d, host.data(), 3 * n);
+    for (uint64_t j = 0; j < n; ++j) {
+      if (sum_col) sum_col[j] = (T)host[j];
+      if (sum_sq) sum_sq[j] = (T)host[n + j];
+      if (cnt) cnt[j] = (uint64_t)host[2 * n + j];
+    }
+  });
+}
+
+template <typename T>
+sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci,
+                       const T* v, const T* mu, uint64_t l, const T* In, T* Out, bool transposed) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(l >= 1 && l <= 128 && In && Out, SAPCA_ERR_ARG, "spmm: panel width must be in [1, 128]");
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    hipStream_t s = h->stream;
+    const int ld = (int)sapca::round_up((int64_t)l, 16);
+    const uint64_t in_rows = transposed ? m : n, out_rows = transposed ? n : m;
+    T* stage = h->scratch2.as<T>(std::max<uint64_t>(in_rows * l, out_rows * l) + n + 2 * 128);
+    T* X = h->panel_x.as<T>(std::max<uint64_t>(in_rows, 1) * ld);
+    T* Y = h->panel_y.as<T>(std::max<uint64_t>(out_rows, 1) * ld);
+    SAPCA_HIP(hipMemcpyAsync(stage, In, in_rows * l * sizeof(T), hipMemcpyHostToDevice, s));
+    sapca::k::add_padding(stage, (int64_t)in_rows, (int)l, X, ld, s);
+    T* d_mu = nullptr;
+    if (mu) {
+      d_mu = h->mean_used_dev.as<T>(n);
+      SAPCA_HIP(hipMemcpyAsync(d_mu, mu, n * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    double* small = h->small.as<double>((size_t)6 * 128 * 128 + 64 + 4 * 128);
+    T* cvec = reinterpret_cast<T*>(small + (size_t)6 * 128 * 128 + 64);
+    T* svec = cvec + 128;
+    SAPCA_HIP(hipStreamSynchronize(s));
+    if (!transposed) {
+      if (mu) sapca::k::weighted_colsum(X, (int64_t)n, ld, d_mu, cvec, h->scratch, s);
+      sapca::k::spmm(A, nullptr, X, ld, Y, ld, ld, mu ? cvec : nullptr, h->opt.spmm_variant, s);
+    } else {
+      int64_t* at_ptr = h->at_ptr.as<int64_t>(n + 1);
+      int32_t* at_idx = h->at_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
+      T* at_val = h->at_val.as<T>(std::max<uint64_t>(nnz, 1));
+      sapca::k::transpose_csr(A, at_ptr, at_idx, at_val, h->scratch, s);
+      CsrView<T> At;
+      At.rows = (int64_t)n; At.cols = (int64_t)m; At.nnz = (int64_t)nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
+      sapca::k::spmm(At, nullptr, X, ld, Y, ld, ld, (const T*)nullptr, h->opt.spmm_variant, s);
+      if (mu) {
+        sapca::k::weighted_colsum(X, (int64_t)m, ld, (const T*)nullptr, svec, h->scratch, s);
+        sapca::k::rank1_subtract(Y, (int64_t)n, ld, d_mu, svec, s);
+      }
+    }
+    sapca::k::strip_padding(Y, (int64_t)out_rows, ld, (int)l, stage, s);
+    download_out(h, stage, Out, (size_t)(out_rows * l));
+  });
+}
+
+template <typename T>
+sapca_status normalize_host(sapca_handle h, int32_t normalizer, uint64_t rows, uint64_t l, T* panel) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(l >= 1 && l <= 128 && panel && rows >= 1, SAPCA_ERR_ARG, "normalize: panel width must be in [1, 128]");
+    SAPCA_CHECK(normalizer >= 0 && normalizer <= 2, SAPCA_ERR_ARG, "unknown normalizer");
+    hipStream_t s = h->stream;
+    const int ld = (int)sapca::round_up((int64_t)l, 16);
+    T* stage = h->scratch.as<T>(rows * l);
+    T* P = h->panel_y.as<T>(rows * ld);
+    SAPCA_HIP(hipMemcpyAsync(stage, panel, rows * l * sizeof(T), hipMemcpyHostToDevice, s));
+    sapca::k::add_padding(stage, (int64_t)rows, (int)l, P, ld, s);
+    Engine<T>::normalize(*h, P, (int64_t)rows, (int)l, ld, normalizer, false, nullptr, nullptr);
+    sapca::k::strip_padding(P, (int64_t)rows, ld, (int)l, stage, s);
+    download_out(h, stage, panel, (size_t)(rows * l));
+  });
+}
+
+template <typename T>
+sapca_status omega_host(sapca_handle h, uint64_t rows, uint64_t l, T* out) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(l >= 1 && l <= 128 && out, SAPCA_ERR_ARG, "omega: panel width must be in [1, 128]");
+    const int ld = (int)sapca::round_up((int64_t)l, 16);
+    T* P = h->panel_x.as<T>(std::max<uint64_t>(rows, 1) * ld);
+    T* stage = h->scratch.as<T>(std::max<uint64_t>(rows * l, 1));
+    sapca::k::gaussian_panel(P, (int64_t)rows, (int)l, ld, h->opt.random_seed, h->stream);
+    sapca::k::strip_padding(P, (int64_t)rows, ld, (int)l, stage, h->stream);
+    download_out(h, stage, out, (size_t)(rows * l));
+  });
+}
+
+}  // namespace
+
+extern "C" {
+
+int sapca_abi_version(void) { return SAPCA_ABI_VERSION; }
+
+void sapca_options_default(sapca_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = (uint32_t)sizeof(sapca_options);
+  o->random_seed = 42;        // sparse/mod.rs:397
+  o->n_components = 50;       // :394
+  o->alpha = 1.0;             // :395
+  o->tolerance = 1e-6;        // :396
+  o->center = 1;              // :398
+  o->verbose = 0;             // :399
+  o->method = SAPCA_LANCZOS;  // pca/mod.rs:64-68
+  o->n_oversamples = 10;
+  o->n_power_iterations = 4;
+  o->normalizer = SAPCA_NORM_QR;
+  o->transform_semantics = SAPCA_TRANSFORM_REFERENCE;
+  o->device_id = -1;
+  o->spmm_variant = 0;
+  o->stream = nullptr;
+}
+
+sapca_status sapca_create(const sapca_options* opts, sapca_handle* out) {
+  if (!out) return SAPCA_ERR_ARG;
+  *out = nullptr;
+  try {
+    sapca_options o;
+    sapca_options_default(&o);
+    if (opts) {
+      SAPCA_CHECK(opts->struct_size == sizeof(sapca_options), SAPCA_ERR_ARG, "sapca_options.struct_size mismatch (ABI)");
+      o = *opts;
+    }
+    SAPCA_CHECK(o.method == SAPCA_LANCZOS || o.method == SAPCA_RANDOM, SAPCA_ERR_ARG, "unknown SVD method");
+    SAPCA_CHECK(o.normalizer >= 0 && o.normalizer <= 2, SAPCA_ERR_ARG, "unknown normalizer");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+      throw Error(SAPCA_ERR_HIP, "no HIP device available: libsapca has no CPU path");
+    sapca_handle h = new sapca_handle_s();
+    h->opt = o;
+    if (o.device_id >= 0) h->device = o.device_id;
+    else SAPCA_HIP(hipGetDevice(&h->device));
+    SAPCA_HIP(hipSetDevice(h->device));
+    if (o.stream) {
+      h->stream = static_cast<hipStream_t>(o.stream);
+    } else {
+      SAPCA_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+      h->own_stream = true;
+    }
+    *out = h;
+    return SAPCA_OK;
+  } catch (const Error& e) {
+    g_create_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_create_error = e.what();
+    return SAPCA_ERR_NOMEM;
+  }
+}
+
+void sapca_destroy(sapca_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->comm.destroy();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* sapca_last_error(sapca_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+sapca_status sapca_set_mask(sapca_handle h, const uint8_t* mask, size_t len) {
+  if (!h) return SAPCA_ERR_ARG;
+  if (len && !mask) return SAPCA_ERR_ARG;
+  h->mask.assign(mask, mask + len);
+  for (auto& b : h->mask) b = b ? 1 : 0;
+  h->mask_version++;
+  h->prep_key.valid = false;
+  return SAPCA_OK;
+}
+
+sapca_status sapca_set_omega_f32(sapca_handle h, const float* omega, size_t rows, size_t cols) {
+  if (!h || ((rows * cols) && !omega)) return SAPCA_ERR_ARG;
+  h->omega.assign(omega, omega + rows * cols);
+  h->omega_rows = rows;
+  h->omega_cols = cols;
+  return SAPCA_OK;
+}
+sapca_status sapca_set_omega_f64(sapca_handle h, const double* omega, size_t rows, size_t cols) {
+  if (!h || ((rows * cols) && !omega)) return SAPCA_ERR_ARG;
+  h->omega.assign(omega, omega + rows * cols);
+  h->omega_rows = rows;
+  h->omega_cols = cols;
+  return SAPCA_OK;
+}
+
+#define SAPCA_DEFINE_TYPED(SUF, T)                                                                                       \
+  sapca_status sapca_fit_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,             \
+                                   const uint64_t* ci, const T* v) {                                                     \
+    return fit_host<T>(h, m, n, nnz, ro, ci, v);                                                                         \
+  }                                                                                                                      \
+  sapca_status sapca_transform_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,       \
+                                         const uint64_t* ci, const T* v, T* out) {                                       \
+    return transform_host<T>(h, m, n, nnz, ro, ci, v, out, false);                                                       \
+  }                                                                                                                      \
+  sapca_status sapca_fit_transform_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,   \
+                                             const uint64_t* ci, const T* v, T* out) {                                   \
+    return transform_host<T>(h, m, n, nnz, ro, ci, v, out, true);                                                        \
+  }                                                                                                                      \
+  sapca_status sapca_fit_csr_device_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p,        \
+                                          const int32_t* i, const T* v) {                                                \
+    return fit_device<T>(h, m, n, nnz, p, i, v);                                                                         \
+  }                                                                                                                      \
+  sapca_status sapca_transform_csr_device_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p,  \
+                                                const int32_t* i, const T* v, T* out) {                                  \
+    return transform_device<T>(h, m, n, nnz, p, i, v, out, false);                                                       \
+  }                                                                                                                      \
+  sapca_status sapca_fit_transform_csr_device_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,                \
+                                                    const int64_t* p, const int32_t* i, const T* v, T* out) {            \
+    return transform_device<T>(h, m, n, nnz, p, i, v, out, true);                                                        \
+  }                                                                                                                      \
+  sapca_status sapca_get_components_##SUF(sapca_handle h, T* out, size_t cap) {                                          \
+    return guarded(h, [&] { get_components<T>(h, out, cap, false); });                                                   \
+  }                                                                                                                      \
+  sapca_status sapca_get_feature_importances_##SUF(sapca_handle h, T* out, size_t cap) {                                 \
+    return guarded(h, [&] { get_components<T>(h, out, cap, true); });                                                    \
+  }                                                                                                                      \
+  sapca_status sapca_get_singular_values_##SUF(sapca_handle h, T* out, size_t cap) {                                     \
+    return guarded(h, [&] { need_fitted(h); copy_out<T>(h->sing, out, cap); });                                          \
+  }                                                                                                                      \
+  sapca_status sapca_get_explained_variance_##SUF(sapca_handle h, T* out, size_t cap) {                                  \
+    return guarded(h, [&] { need_fitted(h); copy_out<T>(h->expl_var, out, cap); });                                      \
+  }                                                                                                                      \
+  sapca_status sapca_get_mean_##SUF(sapca_handle h, T* out, size_t cap) {                                                \
+    return guarded(h, [&] { need_fitted(h); copy_out<T>(h->mean, out, cap); });                                          \
+  }                                                                                                                      \
+  sapca_status sapca_get_explained_variance_ratio_##SUF(sapca_handle h, T* out, size_t cap) {                            \
+    return guarded(h, [&] { get_ratio<T>(h, out, cap, false); });                                                        \
+  }                                                                                                                      \
+  sapca_status sapca_get_cumulative_explained_variance_ratio_##SUF(sapca_handle h, T* out, size_t cap) {                 \
+    return guarded(h, [&] { get_ratio<T>(h, out, cap, true); });                                                         \
+  }                                                                                                                      \
+  sapca_status sapca_colstats_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,        \
+                                        const uint64_t* ci, const T* v, T* sc, T* ssq, uint64_t* cnt) {                  \
+    return colstats_host<T>(h, m, n, nnz, ro, ci, v, sc, ssq, cnt);                                                      \
+  }                                                                                                                      \
+  sapca_status sapca_spmm_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,            \
+                                    const uint64_t* ci, const T* v, const T* mu, uint64_t l, const T* X, T* Y) {         \
+    return spmm_host<T>(h, m, n, nnz, ro, ci, v, mu, l, X, Y, false);                                                    \
+  }                                                                                                                      \
+  sapca_status sapca_spmmt_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,           \
+                                     const uint64_t* ci, const T* v, const T* mu, uint64_t l, const T* Y, T* Z) {        \
+    return spmm_host<T>(h, m, n, nnz, ro, ci, v, mu, l, Y, Z, true);                                                     \
+  }                                                                                                                      \
+  sapca_status sapca_normalize_panel_##SUF(sapca_handle h, int32_t normalizer, uint64_t rows, uint64_t l, T* panel) {    \
+    return normalize_host<T>(h, normalizer, rows, l, panel);                                                             \
+  }                                                                                                                      \
+  sapca_status sapca_generate_omega_##SUF(sapca_handle h, uint64_t rows, uint64_t l, T* out) {                           \
+    return omega_host<T>(h, rows, l, out);                                                                               \
+  }
+
+SAPCA_DEFINE_TYPED(f32, float)
+SAPCA_DEFINE_TYPED(f64, double)
+#undef SAPCA_DEFINE_TYPED
+
+sapca_status sapca_get_dims(sapca_handle h, uint64_t* k, uint64_t* n_used, uint64_t* n_cols) {
+  return guarded(h, [&] {
+    need_fitted(h);
+    if (k) *k = h->k;
+    if (n_used) *n_used = h->n_used;
+    if (n_cols) *n_cols = h->n_cols;
+  });
+}
+
+sapca_status sapca_get_total_variance(sapca_handle h, double* out) {
+  return guarded(h, [&] {
+    need_fitted(h);
+    SAPCA_CHECK(out != nullptr, SAPCA_ERR_ARG, "null output");
+    *out = h->total_var;
+  });
+}
+
+sapca_status sapca_get_mask_index_maps(sapca_handle h, uint64_t* cols_to_use, size_t cap_cols, int64_t* orig_to_masked,
+                                       size_t cap_map) {
+  return guarded(h, [&] {
+    // maps follow the mask currently set (sparse_masked/mod.rs:264-271, :455-466); no fit needed
+    std::vector<uint64_t> cols;
+    std::vector<int64_t> o2m(h->mask.size(), -1);
+    for (size_t j = 0; j < h->mask.size(); ++j)
+      if (h->mask[j]) {
+        o2m[j] = (int64_t)cols.size();
+        cols.push_back((uint64_t)j);
+      }
+    if (cols_to_use) {
+      SAPCA_CHECK(cap_cols >= cols.size(), SAPCA_ERR_ARG, "cols_to_use buffer too small");
+      std::copy(cols.begin(), cols.end(), cols_to_use);
+    }
+    if (orig_to_masked) {
+      SAPCA_CHECK(cap_map >= o2m.size(), SAPCA_ERR_ARG, "orig_to_masked buffer too small");
+      std::copy(o2m.begin(), o2m.end(), orig_to_masked);
+    }
+  });
+}
+
+sapca_status sapca_get_timings(sapca_handle h, sapca_timings* out) {
+  if (!h || !out) return SAPCA_ERR_ARG;
+  *out = h->timings;
+  return SAPCA_OK;
+}
+
+sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint32_t nparts, uint64_t* bounds) {
+  if (!row_offsets || !bounds || nparts == 0) return SAPCA_ERR_ARG;
+  // contiguous ranges balanced by stored entries: boundary p is the first row whose
+  // prefix reaches p/nparts of nnz, kept monotone.
+  const uint64_t nnz = row_offsets[m] - row_offsets[0];
+  bounds[0] = 0;
+  for (uint32_t p = 1; p < nparts; ++p) {
+    const uint64_t target = row_offsets[0] + (uint64_t)((long double)nnz * p / nparts);
+    const uint64_t* it = std::lower_bound(row_offsets, row_offsets + m + 1, target);
+    uint64_t r = (uint64_t)(it - row_offsets);
+    if (r > 0 && r <= m && target - row_offsets[r - 1] < row_offsets[r] - target) r -= 1;  // nearer boundary
+    if (nnz == 0) r = m * p / nparts;
+    if (r > m) r = m;
+    if (r < bounds[p - 1]) r = bounds[p - 1];
+    bounds[p] = r;
+  }
+  bounds[nparts] = m;
+  return SAPCA_OK;
+}
+
+sapca_status sapca_comm_unique_id(uint8_t id[128]) {
+  if (!id) return SAPCA_ERR_ARG;
+  try {
+    sapca::Comm::unique_id(id);
+    return SAPCA_OK;
+  } catch (const Error& e) {
+    g_create_error = e.what();
+    return e.code;
+  }
+}
+
+sapca_status sapca_comm_init_rank(sapca_handle h, uint32_t nranks, uint32_t rank, const uint8_t id[128]) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(id != nullptr, SAPCA_ERR_ARG, "null unique id");
+    h->comm.init_rccl(nranks, rank, id);
+  });
+}
+
+sapca_status sapca_comm_set_callback(sapca_handle h, uint32_t nranks, uint32_t rank, sapca_allreduce_fn fn, void* ctx) {
+  return guarded(h, [&] { h->comm.set_callback(nranks, rank, fn, ctx); });
+}
+
+sapca_status sapca_comm_allreduce(sapca_handle h, void* buf, uint64_t count, int32_t dtype) {
+  return guarded(h, [&] {
+    h->comm.allreduce(buf, count, dtype, h->stream);
+    SAPCA_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+#include "comm.h"
+
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstring>
+#include <mutex>
+
+namespace sapca {
+
+namespace {
+
+// Minimal slice of the RCCL (NCCL-compatible) C API, bound by name at run time.
+struct RcclId { char internal[128]; };
+using ncclComm_t = void*;
+struct RcclApi {
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, RcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* so = nullptr;
+};
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
+
+RcclApi& api() {
+  static RcclApi a;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      a.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a.so) break;
+    }
+    if (!a.so) return;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.so, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.so, "ncclCommInitRank"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.so, "ncclAllReduce"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.so, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.so, "ncclGetErrorString"));
+  });
+  if (!a.so || !a.GetUniqueId || !a.CommInitRank || !a.AllReduce)
+    throw Error(SAPCA_ERR_COMM, "RCCL (librccl.so.1) could not be loaded; use sapca_comm_set_callback instead");
+  return a;
+}
+
+void check(int rc, const char* what) {
+  if (rc != 0) {
+    const char* msg = api().GetErrorString ? api().GetErrorString(rc) : "?";
+    throw Error(SAPCA_ERR_COMM, std::string(what) + ": " + msg);
+  }
+}
+
+}  // namespace
+
+void Comm::unique_id(uint8_t id[128]) {
+  RcclId u;
+  check(api().GetUniqueId(&u), "ncclGetUniqueId");
+  std::memcpy(id, u.internal, 128);
+}
+
+void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
+  destroy();
+  SAPCA_CHECK(nranks_ >= 1 && rank_ < nranks_, SAPCA_ERR_ARG, "comm: rank out of range");
+  nranks = nranks_;
+  rank = rank_;
+  if (nranks == 1) { mode = NONE; return; }
+  RcclId u;
+  std::memcpy(u.internal, id, 128);
+  ncclComm_t c = nullptr;
+  check(api().CommInitRank(&c, (int)nranks, u, (int)rank), "ncclCommInitRank");
+  rccl_comm = c;
+  mode = RCCL;
+}
+
+void Comm::set_callback(uint32_t nranks_, uint32_t rank_, sapca_allreduce_fn f, void* c) {
+  destroy();
+  SAPCA_CHECK(nranks_ >= 1 && rank_ < nranks_, SAPCA_ERR_ARG, "comm: rank out of range");
+  SAPCA_CHECK(f != nullptr || nranks_ == 1, SAPCA_ERR_ARG, "comm: null all-reduce callback");
+  nranks = nranks_;
+  rank = rank_;
+  fn = f;
+  ctx = c;
+  mode = nranks > 1 ? CALLBACK : NONE;
+}
+
+void Comm::allreduce(void* buf, uint64_t count, int dtype, hipStream_t s) {
+  if (!active() || count == 0) return;
+  auto t0 = std::chrono::steady_clock::now();
+  if (mode == RCCL) {
+    check(api().AllReduce(buf, buf, (size_t)count, dtype == 1 ? kNcclFloat64 : kNcclFloat32, kNcclSum, rccl_comm, s),
+          "ncclAllReduce");
+  } else if (mode == CALLBACK) {
+    if (fn(ctx, buf, count, dtype, (void*)s) != 0) throw Error(SAPCA_ERR_COMM, "all-reduce callback reported failure");
+  } else {
+    throw Error(SAPCA_ERR_COMM, "multi-rank handle without a collective");
+  }
+  host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Comm::destroy() {
+  if (mode == RCCL && rccl_comm && api().CommDestroy) (void)api().CommDestroy(rccl_comm);
+  rccl_comm = nullptr;
+  fn = nullptr;
+  ctx = nullptr;
+  mode = NONE;
+  nranks = 1;
+  rank = 0;
+}
+
+}  // namespace sapca

@@ -1,0 +1,127 @@
+// Shared host-side plumbing for libsapca: error propagation, device buffers, views.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sapca.h"
+
+namespace sapca {
+
+struct Error : std::runtime_error {
+  sapca_status code;
+  Error(sapca_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define SAPCA_HIP(expr)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      throw ::sapca::Error(SAPCA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+#define SAPCA_CHECK(cond, code, msg)                 \
+  do {                                               \
+    if (!(cond)) throw ::sapca::Error((code), (msg)); \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+// Grow-only device buffer: repeated fits of the same shape never re-allocate.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  void* ensure(size_t bytes) {
+    if (bytes > cap) {
+      release();
+      size_t want = bytes + bytes / 16 + 256;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) {
+        p = nullptr;
+        throw Error(SAPCA_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+      }
+      cap = want;
+    }
+    return p;
+  }
+  template <typename U>
+  U* as(size_t count) { return static_cast<U*>(ensure(count * sizeof(U))); }
+  template <typename U>
+  U* ptr() const { return static_cast<U*>(p); }
+};
+
+// Non-owning view of a device CSR matrix (rows x cols).
+template <typename T>
+struct CsrView {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  const int64_t* ptr = nullptr;  // [rows+1]
+  const int32_t* idx = nullptr;  // [nnz] ascending within a row
+  const T* val = nullptr;        // [nnz]
+};
+
+// Column-tiled companion of a CsrView for the LDS-staged sweep (see spmm.hip).
+struct TileIndex {
+  int tile_cols = 0;   // panel rows staged per LDS tile
+  int n_tiles = 0;
+  const int32_t* seg = nullptr;  // [rows][n_tiles+1] entry offsets relative to the row start
+};
+
+struct Stream {
+  hipStream_t s = nullptr;
+  bool owned = false;
+};
+
+// HIP-event stopwatch on a stream; a no-op unless enabled.
+struct EventTimer {
+  bool enabled = false;
+  hipStream_t s = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+  struct Span { size_t i; };
+  void begin_collect(hipStream_t st, bool on) {
+    enabled = on;
+    s = st;
+    used = 0;
+  }
+  int start() {
+    if (!enabled) return -1;
+    if (used == pool.size()) {
+      hipEvent_t a, b;
+      SAPCA_HIP(hipEventCreate(&a));
+      SAPCA_HIP(hipEventCreate(&b));
+      pool.emplace_back(a, b);
+    }
+    SAPCA_HIP(hipEventRecord(pool[used].first, s));
+    return (int)used++;
+  }
+  void stop(int i) {
+    if (i >= 0) SAPCA_HIP(hipEventRecord(pool[i].second, s));
+  }
+  double ms(int i) {
+    if (i < 0) return 0.0;
+    float t = 0;
+    SAPCA_HIP(hipEventElapsedTime(&t, pool[i].first, pool[i].second));
+    return t;
+  }
+  ~EventTimer() {
+    for (auto& p : pool) {
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+  }
+};
+
+}  // namespace sapca

@@ -1,0 +1,493 @@
+// Dense tall-skinny panel kernels: the normaliser (R10) and the small-SVD step (R11) of the
+// randomized SVD (single_svdlib::randomized::randomized_svd, call sites
+// /root/reference/src/dimred/pca/sparse/mod.rs:170-180).  The reference's dependency does a
+// serial Householder QR of every m x l panel; any orthonormal basis of the same span gives
+// the same final result, so the panel step here is CholeskyQR2:
+//     G = P^T P   (MFMA, f64 accumulate)  ->  R = chol(G), R^-1  (one workgroup, f64)
+//     P <- P R^-1 (MFMA panel GEMM)       ... twice.
+// MFMA is used only here: these are the path's only dense contractions.
+//
+// v_mfma_f64_16x16x4_f64 lane maps (gfx950): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D: col = lane&15, row = (lane>>4) + 4*reg.
+#include "kernels.h"
+
+namespace sapca {
+namespace k {
+
+namespace {
+
+constexpr int WAVE = 64;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ inline d4 mfma_f64(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------- Gram
+// Upper-triangular tile pairs (ta <= tb) of G = P^T P.  Each wave streams 4-row chunks; the
+// four waves of a block are summed through LDS in a fixed order and the block writes one slab
+// of raw accumulator fragments; gram_reduce_kernel adds the slabs in block order (bitwise
+// reproducible) and unpacks the fragment layout into the full symmetric matrix.
+template <typename T, int NT>
+__global__ void __launch_bounds__(256)
+gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ slabs) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  extern __shared__ double lds[];  // NPAIR * 4 * 64
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int g = lane >> 4, c = lane & 15;
+  d4 acc[NPAIR];
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) acc[p] = d4{0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * 4 * 4;
+  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  double v[NT], nxt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) nxt[t] = (r0 + g < rows) ? (double)P[(r0 + g) * ld + 16 * t + c] : 0.0;
+  for (; r0 < rows; r0 += stride) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = nxt[t];
+    const int64_t rn = r0 + stride + g;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) nxt[t] = (rn < rows) ? (double)P[rn * ld + 16 * t + c] : 0.0;
+    int p = 0;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb) {
+        acc[p] = mfma_f64(v[ta], v[tb], acc[p]);
+        ++p;
+      }
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          double* dst = lds + (p * 4 + reg) * WAVE + lane;
+          if (w == 0) *dst = acc[p][reg]; else *dst += acc[p][reg];
+        }
+    }
+    __syncthreads();
+  }
+  double* slab = slabs + (int64_t)blockIdx.x * NPAIR * 256;
+  for (int i = threadIdx.x; i < NPAIR * 256; i += blockDim.x) slab[i] = lds[i];
+}
+
+__global__ void gram_reduce_kernel(const double* __restrict__ slabs, int nslabs, int nt, int ld, double* __restrict__ G) {
+  const int npair = nt * (nt + 1) / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npair * 256) return;
+  double sum = 0;
+  for (int b = 0; b < nslabs; ++b) sum += slabs[(int64_t)b * npair * 256 + i];
+  int p = i / 256, rem = i % 256, reg = rem / 64, lane = rem % 64;
+  int ta = 0;
+  while (p >= nt - ta) { p -= nt - ta; ++ta; }
+  const int tb = ta + p;
+  const int row = 16 * ta + (lane >> 4) + 4 * reg, col = 16 * tb + (lane & 15);
+  G[row * ld + col] = sum;
+  G[col * ld + row] = sum;
+}
+
+// ---------------------------------------------------------------- Cholesky + inverse
+// One workgroup.  R upper with G = R^T R on the leading l x l block.  A pivot that falls below
+// 1e-13 of its original diagonal (rank-deficient panel) is replaced by that floor and counted
+// in *info; the direction it produces carries a ~zero singular value downstream.
+__global__ void __launch_bounds__(256)
+chol_inv_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
+                int* __restrict__ info) {
+  extern __shared__ double a[];  // l x l working copy (row-major, stride l)
+  __shared__ double pivot;
+  __shared__ int bad;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  if (tid == 0) bad = 0;
+  for (int i = tid; i < l * l; i += nth) a[i] = G[(i / l) * ld + (i % l)];
+  __syncthreads();
+  double scale = 0;
+  for (int i = 0; i < l; ++i) scale = fmax(scale, fabs(G[i * ld + i]));
+  for (int kk = 0; kk < l; ++kk) {
+    if (tid == 0) {
+      double d = a[kk * l + kk];
+      const double floor_ = fmax(fabs(G[kk * ld + kk]), scale * 1e-3) * 1e-13 + 1e-300;
+      if (!(d > floor_)) { d = floor_; bad += 1; }
+      pivot = sqrt(d);
+      a[kk * l + kk] = pivot;
+    }
+    __syncthreads();
+    const double inv = 1.0 / pivot;
+    for (int j = kk + 1 + tid; j < l; j += nth) a[kk * l + j] *= inv;
+    __syncthreads();
+    const int rem = l - kk - 1;
+    for (int t = tid; t < rem * rem; t += nth) {
+      const int i = kk + 1 + t / rem, j = kk + 1 + t % rem;
+      if (j >= i) a[i * l + j] -= a[kk * l + i] * a[kk * l + j];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < ld * ld; i += nth) {
+    const int r = i / ld, c2 = i % ld;
+    R[i] = (r < l && c2 < l && c2 >= r) ? a[r * l + c2] : 0.0;
+    Rinv[i] = 0.0;
+  }
+  __syncthreads();
+  // column j of R^-1 by back substitution; one thread per column, reading R from LDS
+  for (int j = tid; j < l; j += nth) {
+    Rinv[j * ld + j] = 1.0 / a[j * l + j];
+    for (int i = j - 1; i >= 0; --i) {
+      double s = 0;
+      for (int t = i + 1; t <= j; ++t) s += a[i * l + t] * Rinv[t * ld + j];
+      Rinv[i * ld + j] = -s / a[i * l + i];
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && bad) atomicAdd(info, bad);
+}
+
+// ---------------------------------------------------------------- panel GEMM
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+  __device__ static inline void load(const float* p, double out[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+};
+template <> struct Quad<double> {
+  __device__ static inline void load(const double* p, double out[4]) {
+    const double2 a = *reinterpret_cast<const double2*>(p);
+    const double2 b = *reinterpret_cast<const double2*>(p + 2);
+    out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+  }
+};
+
+// out[16-row tile] = P[tile] * M.  Lane (i = lane&15, g = lane>>4) loads the 16-byte segments
+// P[r0+i][16j+4g .. +3]; k-slot g of MFMA step (j, e) is panel column 16j+4g+e on both operands.
+template <typename T, int NTO>
+__global__ void __launch_bounds__(256)
+panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out) {
+  extern __shared__ double Ms[];  // ld x ldo
+  for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) Ms[i] = M[i];
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = threadIdx.x / WAVE;
+  const int i = lane & 15, g = lane >> 4;
+  const int nt = ld / 16;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = tile * 16;
+    const bool row_ok = r0 + i < rows;
+    const T* prow = P + (row_ok ? (r0 + i) : 0) * ld + 4 * g;
+    d4 acc[NTO];
+#pragma unroll
+    for (int tb = 0; tb < NTO; ++tb) acc[tb] = d4{0, 0, 0, 0};
+    for (int j = 0; j < nt; ++j) {
+      double a4[4] = {0, 0, 0, 0};
+      if (row_ok) Quad<T>::load(prow + 16 * j, a4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double* brow = Ms + (16 * j + 4 * g + e) * ldo + i;
+#pragma unroll
+        for (int tb = 0; tb < NTO; ++tb) acc[tb] = mfma_f64(a4[e], brow[16 * tb], acc[tb]);
+      }
+    }
+#pragma unroll
+    for (int tb = 0; tb < NTO; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = r0 + g + 4 * reg;
+        if (r < rows) out[r * ldo + 16 * tb + i] = (T)acc[tb][reg];
+      }
+  }
+}
+
+// ---------------------------------------------------------------- reductions / elementwise
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ P, int64_t rows, int ld, const T* __restrict__ w,
+                                      double* __restrict__ partial) {
+  extern __shared__ double red[];  // blockDim.y * ld
+  const int j = threadIdx.x;
+  double s = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += (int64_t)gridDim.x * blockDim.y)
+    s += (w ? (double)w[r] : 1.0) * (double)P[r * ld + j];
+  red[threadIdx.y * ld + j] = s;
+  __syncthreads();
+  if (threadIdx.y == 0) {
+    for (int y = 1; y < (int)blockDim.y; ++y) s += red[y * ld + j];
+    partial[(int64_t)blockIdx.x * ld + j] = s;
+  }
+}
+
+template <typename T>
+__global__ void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int ld, T* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ld) return;
+  double s = 0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * ld + j];
+  out[j] = (T)s;
+}
+
+template <typename T>
+__global__ void rank1_subtract_kernel(T* __restrict__ Z, int64_t rows, int ld, const T* __restrict__ mu,
+                                      const T* __restrict__ svec) {
+  const int64_t total = rows * ld;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t r = i / ld;
+    Z[i] -= mu[r] * svec[i - r * ld];
+  }
+}
+
+// sign of the largest-|.| entry of column r of VtT (first row index on ties)
+template <typename T>
+__global__ void __launch_bounds__(256)
+flip_sign_kernel(const T* __restrict__ VtT, int64_t n, int ld, double* __restrict__ sign) {
+  __shared__ double best_a[256];
+  __shared__ long long best_i[256];
+  const int r = blockIdx.x;
+  double ba = -1.0;
+  long long bi = 0x7fffffffffffffffLL;
+  for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
+    const double a = fabs((double)VtT[j * ld + r]);
+    if (a > ba) { ba = a; bi = j; }
+  }
+  best_a[threadIdx.x] = ba;
+  best_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const double oa = best_a[threadIdx.x + off];
+      const long long oi = best_i[threadIdx.x + off];
+      if (oa > best_a[threadIdx.x] || (oa == best_a[threadIdx.x] && oi < best_i[threadIdx.x])) {
+        best_a[threadIdx.x] = oa;
+        best_i[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sign[r] = (n > 0 && (double)VtT[best_i[0] * ld + r] < 0) ? -1.0 : 1.0;
+}
+
+template <typename T>
+__global__ void flip_transpose_kernel(const T* __restrict__ VtT, int64_t n, int ld, int k,
+                                      const double* __restrict__ sign, T* __restrict__ comps) {
+  const int64_t total = (int64_t)k * n;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t r = i / n, j = i - r * n;
+    comps[i] = (T)(sign[r] * (double)VtT[j * ld + r]);
+  }
+}
+
+template <typename T>
+__global__ void scaled_transpose_kernel(const T* __restrict__ comps, int64_t n, int k, const double* __restrict__ scale,
+                                        T* __restrict__ W, int ld) {
+  const int64_t total = n * ld;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t j = i / ld;
+    const int r = (int)(i - j * ld);
+    W[i] = r < k ? (T)((scale ? scale[j] : 1.0) * (double)comps[(int64_t)r * n + j]) : (T)0;
+  }
+}
+
+template <typename T>
+__global__ void fill_zero_kernel(T* p, int64_t count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) p[i] = (T)0;
+}
+
+template <typename T>
+__global__ void convert_kernel(const double* __restrict__ in, T* __restrict__ out, int64_t count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) out[i] = (T)in[i];
+}
+
+template <typename T>
+__global__ void repad_kernel(const T* __restrict__ in, int64_t rows, int ld_in, int ncols, T* __restrict__ out, int ld_out) {
+  const int64_t total = rows * ld_out;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t r = i / ld_out;
+    const int c = (int)(i - r * ld_out);
+    out[i] = c < ncols ? in[r * ld_in + c] : (T)0;
+  }
+}
+
+inline int grid_for(int64_t work_items, int block, int cap = 4096) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+template <typename T, int NT>
+void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, hipStream_t s) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  const size_t lds = (size_t)NPAIR * 256 * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<T, NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gram_kernel<T, NT>), dim3(nblocks), dim3(256), lds, s, P, rows, ld, slabs);
+}
+
+template <typename T, int NTO>
+void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s) {
+  const size_t lds = (size_t)ld * ldo * sizeof(double);
+  static size_t attr_bytes = 0;
+  if (lds > 48 * 1024 && lds > attr_bytes) {
+    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  const int64_t ntiles = (rows + 15) / 16;
+  int blocks = (int)((ntiles + 3) / 4);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((panel_gemm_kernel<T, NTO>), dim3(blocks), dim3(256), lds, s, P, rows, ld, M, ldo, out);
+}
+
+}  // namespace
+
+template <typename T>
+void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s) {
+  SAPCA_CHECK(ld % 16 == 0 && ld >= 16 && ld <= 128, SAPCA_ERR_ARG, "panel width (n_components + n_oversamples) above 128 is not supported");
+  const int nt = ld / 16;
+  const int npair = nt * (nt + 1) / 2;
+  int nblocks = (int)((rows + 15) / 16);
+  if (nblocks > 512) nblocks = 512;
+  if (nblocks < 1) nblocks = 1;
+  double* slabs = scratch.as<double>((size_t)nblocks * npair * 256);
+  switch (nt) {
+    case 1: launch_gram<T, 1>(P, rows, ld, slabs, nblocks, s); break;
+    case 2: launch_gram<T, 2>(P, rows, ld, slabs, nblocks, s); break;
+    case 3: launch_gram<T, 3>(P, rows, ld, slabs, nblocks, s); break;
+    case 4: launch_gram<T, 4>(P, rows, ld, slabs, nblocks, s); break;
+    case 5: launch_gram<T, 5>(P, rows, ld, slabs, nblocks, s); break;
+    case 6: launch_gram<T, 6>(P, rows, ld, slabs, nblocks, s); break;
+    case 7: launch_gram<T, 7>(P, rows, ld, slabs, nblocks, s); break;
+    default: launch_gram<T, 8>(P, rows, ld, slabs, nblocks, s); break;
+  }
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 255) / 256), dim3(256), 0, s, slabs, nblocks, nt, ld, G);
+  SAPCA_HIP(hipGetLastError());
+}
+
+void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
+  const size_t lds = (size_t)l * l * sizeof(double);
+  static size_t attr_bytes = 0;
+  if (lds > 48 * 1024 && lds > attr_bytes) {
+    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes = lds;
+  }
+  hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds, s, G, l, ld, R, Rinv, info);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s) {
+  SAPCA_CHECK(ld % 16 == 0 && ldo % 16 == 0 && ld <= 128 && ldo <= 128 && ldo >= 16, SAPCA_ERR_ARG, "panel_gemm: unsupported panel width");
+  SAPCA_CHECK(out != P || ldo == ld, SAPCA_ERR_ARG, "panel_gemm: in-place needs ldo == ld");
+  if (rows == 0) return;
+  switch (ldo / 16) {
+    case 1: launch_panel_gemm<T, 1>(P, rows, ld, M, ldo, out, s); break;
+    case 2: launch_panel_gemm<T, 2>(P, rows, ld, M, ldo, out, s); break;
+    case 3: launch_panel_gemm<T, 3>(P, rows, ld, M, ldo, out, s); break;
+    case 4: launch_panel_gemm<T, 4>(P, rows, ld, M, ldo, out, s); break;
+    case 5: launch_panel_gemm<T, 5>(P, rows, ld, M, ldo, out, s); break;
+    case 6: launch_panel_gemm<T, 6>(P, rows, ld, M, ldo, out, s); break;
+    case 7: launch_panel_gemm<T, 7>(P, rows, ld, M, ldo, out, s); break;
+    default: launch_panel_gemm<T, 8>(P, rows, ld, M, ldo, out, s); break;
+  }
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void weighted_colsum(const T* P, int64_t rows, int ld, const T* w, T* out, DevBuf& scratch, hipStream_t s) {
+  int by = 256 / ld;
+  if (by < 1) by = 1;
+  int nblocks = (int)((rows + by * 8 - 1) / (by * 8));
+  if (nblocks > 512) nblocks = 512;
+  if (nblocks < 1) nblocks = 1;
+  double* partial = scratch.as<double>((size_t)nblocks * ld);
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(nblocks), dim3(ld, by), (size_t)by * ld * sizeof(double), s, P,
+                     rows, ld, w, partial);
+  hipLaunchKernelGGL((colsum_final_kernel<T>), dim3((ld + 63) / 64), dim3(64), 0, s, partial, nblocks, ld, out);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void rank1_subtract(T* Z, int64_t rows, int ld, const T* mu, const T* svec, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL((rank1_subtract_kernel<T>), dim3(grid_for(rows * ld, 256)), dim3(256), 0, s, Z, rows, ld, mu, svec);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s) {
+  double* sign = scratch.as<double>(k);
+  hipLaunchKernelGGL((flip_sign_kernel<T>), dim3(k), dim3(256), 0, s, VtT, n, ld, sign);
+  hipLaunchKernelGGL((flip_transpose_kernel<T>), dim3(grid_for((int64_t)k * n, 256)), dim3(256), 0, s, VtT, n, ld, k,
+                     sign, components);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void scaled_transpose(const T* comps, int64_t n, int k, const double* scale, T* W, int ld, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL((scaled_transpose_kernel<T>), dim3(grid_for(n * ld, 256)), dim3(256), 0, s, comps, n, k, scale, W, ld);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void fill_zero(T* p, int64_t count, hipStream_t s) {
+  if (count == 0) return;
+  hipLaunchKernelGGL((fill_zero_kernel<T>), dim3(grid_for(count, 256)), dim3(256), 0, s, p, count);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void convert_from_f64(const double* in, T* out, int64_t count, hipStream_t s) {
+  if (count == 0) return;
+  hipLaunchKernelGGL((convert_kernel<T>), dim3(grid_for(count, 256)), dim3(256), 0, s, in, out, count);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void strip_padding(const T* in, int64_t rows, int ld, int ncols, T* out, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL((repad_kernel<T>), dim3(grid_for(rows * ncols, 256)), dim3(256), 0, s, in, rows, ld, ncols, out, ncols);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void add_padding(const T* in, int64_t rows, int ncols, T* out, int ld, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL((repad_kernel<T>), dim3(grid_for(rows * ld, 256)), dim3(256), 0, s, in, rows, ncols, ncols, out, ld);
+  SAPCA_HIP(hipGetLastError());
+}
+
+#define INSTANTIATE(T)                                                                            \
+  template void gram<T>(const T*, int64_t, int, double*, DevBuf&, hipStream_t);                   \
+  template void panel_gemm<T>(const T*, int64_t, int, const double*, int, T*, hipStream_t);       \
+  template void weighted_colsum<T>(const T*, int64_t, int, const T*, T*, DevBuf&, hipStream_t);   \
+  template void rank1_subtract<T>(T*, int64_t, int, const T*, const T*, hipStream_t);             \
+  template void flip_transpose<T>(const T*, int64_t, int, int, T*, DevBuf&, hipStream_t);         \
+  template void scaled_transpose<T>(const T*, int64_t, int, const double*, T*, int, hipStream_t); \
+  template void fill_zero<T>(T*, int64_t, hipStream_t);                                           \
+  template void convert_from_f64<T>(const double*, T*, int64_t, hipStream_t);                     \
+  template void strip_padding<T>(const T*, int64_t, int, int, T*, hipStream_t);                   \
+  template void add_padding<T>(const T*, int64_t, int, T*, int, hipStream_t);
+INSTANTIATE(float)
+INSTANTIATE(double)
+template void fill_zero<int>(int*, int64_t, hipStream_t);
+#undef INSTANTIATE
+
+}  // namespace k
+}  // namespace sapca

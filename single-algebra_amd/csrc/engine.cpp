@@ -1,0 +1,474 @@
+// Host orchestration of the sparse-PCA hot path on one GPU (one rank of a row-sharded job).
+// Mirrors, step by step:
+//   SparsePCA::fit            /root/reference/src/dimred/pca/sparse/mod.rs:102-242
+//   MaskedSparsePCA::fit      /root/reference/src/dimred/pca/sparse_masked/mod.rs:255-419
+//   SparsePCA::transform      sparse/mod.rs:255-285   (quirk Q2)
+//   MaskedSparsePCA::transform sparse_masked/mod.rs:438-546 (quirk Q3)
+// with the single-svdlib calls (randomized_svd, svd_las2, svd_flip, MaskedCSRMatrix) realised
+// by the kernels in this directory.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "lanczos.h"
+#include "small_svd.h"
+
+namespace sapca {
+
+namespace {
+
+constexpr size_t kSmallDoubles = (size_t)6 * 128 * 128 + 64 + 4 * 128;
+
+enum Cat { C_PREPARE, C_STATS, C_SPMM, C_SPMMT, C_ORTHO, C_SMALL, C_LANCZOS, C_TRANSFORM, C_COUNT };
+
+struct Scope {
+  sapca_handle_s& h;
+  int ev;
+  Scope(sapca_handle_s& h_, int cat) : h(h_), ev(h_.timer.start()) {
+    if (ev >= 0) h.spans.emplace_back(cat, ev);
+  }
+  ~Scope() {
+    try { h.timer.stop(ev); } catch (...) {}
+  }
+};
+
+void collect_timings(sapca_handle_s& h, bool is_fit) {
+  if (!h.timer.enabled) return;
+  sapca_timings& t = h.timings;
+  if (is_fit) {
+    const double keep_upload = t.upload_ms;
+    std::memset(&t, 0, sizeof(t));
+    t.upload_ms = keep_upload;
+  } else {
+    t.transform_ms = 0;
+  }
+  for (auto& sp : h.spans) {
+    const double ms = h.timer.ms(sp.second);
+    switch (sp.first) {
+      case C_PREPARE: t.prepare_ms += ms; break;
+      case C_STATS: t.stats_ms += ms; break;
+      case C_SPMM:
+        t.spmm_ms += ms;
+        if (t.n_spmm < 32) t.spmm_sweep_ms[t.n_spmm] = ms;
+        t.n_spmm++;
+        break;
+      case C_SPMMT:
+        t.spmmt_ms += ms;
+        if (t.n_spmmt < 32) t.spmmt_sweep_ms[t.n_spmmt] = ms;
+        t.n_spmmt++;
+        break;
+      case C_ORTHO: t.ortho_ms += ms; break;
+      case C_SMALL: t.small_svd_ms += ms; break;
+      case C_LANCZOS: t.lanczos_ms += ms; break;
+      case C_TRANSFORM: t.transform_ms += ms; break;
+      default: break;
+    }
+  }
+  t.comm_ms = h.comm.host_ms;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// prepare: A^T, column statistics, mask compaction.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void Engine<T>::prepare(H& h, const CsrView<T>& A) {
+  hipStream_t s = h.stream;
+  const int64_t m = A.rows, n = A.cols, nnz = A.nnz;
+  const bool masked = !h.mask.empty();
+  if (masked && (int64_t)h.mask.size() != n)  // sparse_masked/mod.rs:258-262
+    throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
+  h.prep_key.valid = false;
+
+  CsrView<T> At;
+  {
+    Scope sc(h, C_PREPARE);
+    int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
+    int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    T* at_val = h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s);
+    At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
+  }
+
+  // R1/R2 (csr.rs:259-312, 558-608) as row sums of A^T, plus the per-column stored-entry count.
+  std::vector<double> sums((size_t)2 * n + 1, 0.0);
+  {
+    Scope sc(h, C_STATS);
+    double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+    k::row_sums(At, d_stats, d_stats + n, s);
+    k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
+    const double m_local = (double)m;
+    SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &m_local, sizeof(double), hipMemcpyHostToDevice, s));
+    if (h.comm.active()) h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s);
+    SAPCA_HIP(hipMemcpyAsync(sums.data(), d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(&sums[(size_t)2 * n], d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+  }
+  h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
+  const double mg = (double)h.m_global;
+
+  // mask index maps (sparse_masked/mod.rs:264-271 and the HashMap of :462-466)
+  h.cols_to_use.clear();
+  h.orig_to_masked.clear();
+  h.has_mask_maps = masked;
+  if (masked) {
+    h.orig_to_masked.assign((size_t)n, -1);
+    for (int64_t j = 0; j < n; ++j)
+      if (h.mask[(size_t)j]) {
+        h.orig_to_masked[(size_t)j] = (int64_t)h.cols_to_use.size();
+        h.cols_to_use.push_back((uint64_t)j);
+      }
+  }
+  const int64_t n_used = masked ? (int64_t)h.cols_to_use.size() : n;
+
+  // R3: mean and total variance (sparse/mod.rs:106-131; masked :273-311, over cols_to_use only)
+  h.prep_mean.assign((size_t)n, 0.0);
+  h.prep_total_var = 0;
+  if (h.opt.center) {
+    for (int64_t j = 0; j < n; ++j) h.prep_mean[(size_t)j] = (double)(T)(sums[(size_t)j] / mg);
+    auto var_of = [&](int64_t j) {
+      const double mean = sums[(size_t)j] / mg;
+      return (sums[(size_t)n + j] - mean * sums[(size_t)j]) / (mg - 1.0);
+    };
+    if (masked) for (uint64_t j : h.cols_to_use) h.prep_total_var += var_of((int64_t)j);
+    else for (int64_t j = 0; j < n; ++j) h.prep_total_var += var_of(j);
+  }
+
+  // operator seen by the SVD engines: MaskedCSRMatrix::new (sparse_masked/mod.rs:313)
+  if (masked) {
+    Scope sc(h, C_PREPARE);
+    std::vector<int32_t> o2m32((size_t)n), sel((size_t)std::max<int64_t>(n_used, 1));
+    for (int64_t j = 0; j < n; ++j) o2m32[(size_t)j] = (int32_t)h.orig_to_masked[(size_t)j];
+    for (int64_t j = 0; j < n_used; ++j) sel[(size_t)j] = (int32_t)h.cols_to_use[(size_t)j];
+    int32_t* d_o2m = h.o2m_dev.as<int32_t>((size_t)std::max<int64_t>(n, 1));
+    int32_t* d_sel = h.sel_rows_dev.as<int32_t>((size_t)std::max<int64_t>(n_used, 1));
+    SAPCA_HIP(hipMemcpyAsync(d_o2m, o2m32.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    SAPCA_HIP(hipMemcpyAsync(d_sel, sel.data(), (size_t)n_used * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
+    int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    int64_t nnz_used = 0, nnz_used_t = 0;
+    k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s);
+    int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
+    int32_t* cat_idx = h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    T* cat_val = h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    k::select_rows(At, d_sel, n_used, cat_ptr, cat_idx, cat_val, &nnz_used_t, h.scratch, s);
+    SAPCA_CHECK(nnz_used == nnz_used_t, SAPCA_ERR_HIP, "internal: mask compaction of A and A^T disagree");
+    h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
+    h.at_used = {n_used, m, nnz_used, cat_ptr, cat_idx, cat_val};
+  } else {
+    h.a_used = {m, n, nnz, A.ptr, A.idx, A.val};
+    h.at_used = {n, m, nnz, At.ptr, At.idx, At.val};
+  }
+
+  h.prep_key.ptr = A.ptr; h.prep_key.idx = A.idx; h.prep_key.val = A.val;
+  h.prep_key.m = (uint64_t)m; h.prep_key.n = (uint64_t)n; h.prep_key.nnz = (uint64_t)nnz;
+  h.prep_key.mask_version = h.mask_version; h.prep_key.dtype = kDtype; h.prep_key.valid = true;
+}
+
+// ------------------------------------------------------------------------------------------
+// R10: PowerIterationNormalizer on a rows x ld panel (CholeskyQR, f64 Gram on MFMA).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2) {
+  if (normalizer == SAPCA_NORM_NONE) return;
+  hipStream_t s = h.stream;
+  Scope sc(h, C_ORTHO);
+  double* base = h.small.as<double>(kSmallDoubles);
+  double* G = base;
+  double* Rinv = base + (size_t)ld * ld;
+  double* Rtmp = base + (size_t)2 * ld * ld;
+  int* info = reinterpret_cast<int*>(base + (size_t)6 * 128 * 128);
+  // QR -> CholeskyQR2 (orthonormal to working precision); LU -> one pass: a well-conditioned
+  // basis of the same span, which is all the reference's LU normaliser provides.
+  const int passes = normalizer == SAPCA_NORM_QR ? 2 : 1;
+  for (int pass = 0; pass < passes; ++pass) {
+    k::gram(P, rows, ld, G, h.scratch2, s);
+    if (sharded && h.comm.active()) h.comm.allreduce(G, (uint64_t)ld * ld, 1, s);
+    double* Rout = pass == 0 ? (R1 ? R1 : Rtmp) : (R2 ? R2 : Rtmp);
+    k::chol_inv(G, l, ld, Rout, Rinv, info, s);
+    k::panel_gemm(P, rows, ld, Rinv, ld, P, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// R7-R11, R13: randomized SVD of the (implicitly centred) prepared operator.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void Engine<T>::fit_randomized(H& h) {
+  hipStream_t s = h.stream;
+  const CsrView<T> A = view(h.a_used), At = view(h.at_used);
+  const int64_t m = A.rows, n_used = A.cols;
+  const int k = (int)h.opt.n_components;
+  const int64_t l_req = (int64_t)h.opt.n_components + (int64_t)h.opt.n_oversamples;
+  const int l = (int)std::min<int64_t>(l_req, std::min<int64_t>((int64_t)h.m_global, n_used));
+  SAPCA_CHECK(l <= 128, SAPCA_ERR_ARG, "n_components + n_oversamples above 128 is not supported");
+  const int ld = (int)round_up(l, 16);
+  const int q = (int)h.opt.n_power_iterations;
+  const int norm = h.opt.normalizer;
+  const bool center = h.opt.center != 0;
+  const int variant = h.opt.spmm_variant;
+
+  T* X = h.panel_x.as<T>((size_t)std::max<int64_t>(n_used, 1) * ld);
+  T* Y = h.panel_y.as<T>((size_t)std::max<int64_t>(m, 1) * ld);
+  double* small = h.small.as<double>(kSmallDoubles);
+  double* R1 = small + (size_t)3 * ld * ld;
+  double* R2 = small + (size_t)4 * ld * ld;
+  double* Mdev = small + (size_t)5 * ld * ld;
+  int* info = reinterpret_cast<int*>(small + (size_t)6 * 128 * 128);
+  T* cvec = reinterpret_cast<T*>(small + (size_t)6 * 128 * 128 + 64);
+  T* svec = cvec + 128;
+  const T* mu = center ? h.mean_used_dev.ptr<T>() : nullptr;
+  SAPCA_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
+
+  // Omega: injected (parity tests) or generated from the seed
+  if (!h.omega.empty()) {
+    SAPCA_CHECK((int64_t)h.omega_rows == n_used && (int64_t)h.omega_cols >= l, SAPCA_ERR_ARG,
+                "injected Omega must be (features seen by the SVD) x (n_components + n_oversamples)");
+    std::vector<T> tmp((size_t)n_used * l);
+    for (int64_t r = 0; r < n_used; ++r)
+      for (int j = 0; j < l; ++j) tmp[(size_t)r * l + j] = (T)h.omega[(size_t)r * h.omega_cols + j];
+    T* stage = h.scratch2.as<T>(tmp.size());
+    SAPCA_HIP(hipMemcpyAsync(stage, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    k::add_padding(stage, n_used, l, X, ld, s);
+    SAPCA_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
+  } else {
+    k::gaussian_panel(X, n_used, l, ld, h.opt.random_seed, s);
+  }
+
+  auto sweep_A = [&]() {  // Y = Ac X   (R8)
+    if (center) k::weighted_colsum(X, n_used, ld, mu, cvec, h.scratch2, s);
+    Scope sc(h, C_SPMM);
+    k::spmm(A, h.tiles_a.seg ? &h.tiles_a : nullptr, X, ld, Y, ld, ld, center ? cvec : nullptr, variant, s);
+  };
+  auto sweep_At = [&]() {  // X = Ac^T Y   (R9); partial products are summed over ranks
+    {
+      Scope sc(h, C_SPMMT);
+      k::spmm(At, h.tiles_at.seg ? &h.tiles_at : nullptr, Y, ld, X, ld, ld, (const T*)nullptr, variant, s);
+    }
+    if (h.comm.active()) h.comm.allreduce(X, (uint64_t)n_used * ld, kDtype, s);
+    if (center) {
+      k::weighted_colsum(Y, m, ld, (const T*)nullptr, svec, h.scratch2, s);
+      if (h.comm.active()) h.comm.allreduce(svec, (uint64_t)ld, kDtype, s);
+      k::rank1_subtract(X, n_used, ld, mu, svec, s);
+    }
+  };
+
+  for (int it = 0; it < q; ++it) {
+    sweep_A();
+    normalize(h, Y, m, l, ld, norm, true, nullptr, nullptr);
+    sweep_At();
+    normalize(h, X, n_used, l, ld, norm, false, nullptr, nullptr);
+  }
+  sweep_A();
+  normalize(h, Y, m, l, ld, SAPCA_NORM_QR, true, nullptr, nullptr);  // Q = qr(Y): always orthonormal
+  sweep_At();                                                       // X = B^T = Ac^T Q  (n_used x l)
+
+  // R11: SVD of B through a QR of B^T: B^T = Qz Rz, Rz = Ur S Vr^T  =>  vt = (Qz Ur)^T.
+  std::vector<double> r1((size_t)ld * ld), r2((size_t)ld * ld);
+  int info_host = 0;
+  {
+    Scope sc(h, C_SMALL);
+    normalize(h, X, n_used, l, ld, SAPCA_NORM_QR, false, R1, R2);
+    SAPCA_HIP(hipMemcpyAsync(r1.data(), R1, r1.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(r2.data(), R2, r2.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(&info_host, info, sizeof(int), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+    std::vector<double> Rz((size_t)l * l, 0.0), Ur, sv;
+    for (int i = 0; i < l; ++i)
+      for (int j = i; j < l; ++j) {
+        double acc = 0;
+        for (int t = i; t <= j; ++t) acc += r2[(size_t)i * ld + t] * r1[(size_t)t * ld + j];
+        Rz[(size_t)i * l + j] = acc;
+      }
+    jacobi_svd(Rz, l, Ur, sv);
+    for (int i = 0; i < l; ++i)
+      SAPCA_CHECK(std::isfinite(sv[i]), SAPCA_ERR_SVD, "Randomized SVD computation failed: non-finite singular value");
+    const int ldk = (int)round_up(k, 16);
+    std::vector<double> M((size_t)ld * ldk, 0.0);
+    for (int i = 0; i < l; ++i)
+      for (int j = 0; j < k; ++j) M[(size_t)i * ldk + j] = Ur[(size_t)i * l + j];
+    SAPCA_HIP(hipMemcpyAsync(Mdev, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    T* VtT = h.panel_w.as<T>((size_t)std::max<int64_t>(n_used, 1) * ldk);
+    k::panel_gemm(X, n_used, ld, Mdev, ldk, VtT, s);
+    T* comps = h.components_dev.as<T>((size_t)k * std::max<int64_t>(n_used, 1));
+    k::flip_transpose(VtT, n_used, ldk, k, comps, h.scratch2, s);  // R13
+    SAPCA_HIP(hipStreamSynchronize(s));                            // M goes out of scope
+    h.sing.assign(sv.begin(), sv.begin() + k);
+  }
+  h.chol_regularised = info_host;
+}
+
+// ------------------------------------------------------------------------------------------
+// R12: Lanczos on the raw operator (no centring: quirk Q1).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void Engine<T>::fit_lanczos(H& h) {
+  Scope sc(h, C_LANCZOS);
+  lanczos_fit<T>(h);
+}
+
+// ------------------------------------------------------------------------------------------
+// fit
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void Engine<T>::fit(H& h, const CsrView<T>& A) {
+  hipStream_t s = h.stream;
+  h.spans.clear();
+  h.comm.host_ms = 0;
+  h.timer.begin_collect(s, h.opt.collect_timings != 0);
+  const int total_ev = h.timer.start();
+  h.fitted = false;
+  SAPCA_CHECK(h.opt.n_components > 0, SAPCA_ERR_ARG, "n_components must be positive");
+  SAPCA_CHECK(A.rows > 0 && A.cols > 0, SAPCA_ERR_ARG, "empty matrix");
+  prepare(h, A);
+  const int64_t n_used = h.a_used.cols;
+  if (n_used == 0) throw Error(SAPCA_ERR_SVD, "SVD computation failed: the mask selects no feature");
+  if ((int64_t)h.opt.n_components > std::min<int64_t>((int64_t)h.m_global, n_used))
+    throw Error(SAPCA_ERR_SVD, std::string(h.opt.method == SAPCA_RANDOM ? "Randomized SVD" : "SVD") +
+                                   " computation failed: n_components exceeds the matrix dimensions");
+  SAPCA_CHECK(h.m_global >= 2, SAPCA_ERR_ARG, "need at least two samples");
+
+  // column means of the features the SVD sees, in T (the centring vector of the sweeps and of transform)
+  {
+    std::vector<T> mu((size_t)n_used);
+    for (int64_t j = 0; j < n_used; ++j) {
+      const int64_t src = h.has_mask_maps ? (int64_t)h.cols_to_use[(size_t)j] : j;
+      mu[(size_t)j] = (T)h.prep_mean[(size_t)src];
+    }
+    T* d_mu = h.mean_used_dev.as<T>((size_t)n_used);
+    SAPCA_HIP(hipMemcpyAsync(d_mu, mu.data(), mu.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+  }
+
+  if (h.opt.method == SAPCA_RANDOM) fit_randomized(h);
+  else fit_lanczos(h);
+
+  h.k = h.opt.n_components;
+  h.n_used = (uint64_t)n_used;
+  h.n_cols = (uint64_t)A.cols;
+  h.m_fit = h.m_global;
+  h.dtype = kDtype;
+  // sparse/mod.rs:106-117: mean_ = col_sums / n when centring, zeros otherwise (the reference
+  // allocates zeros(n_samples) there -- a length bug that is never read; n_cols zeros here).
+  h.mean = h.prep_mean;
+  const double nm1 = (double)(h.m_fit - 1);
+  h.expl_var.resize(h.k);
+  for (uint64_t i = 0; i < h.k; ++i) {  // sparse/mod.rs:210-216
+    const T sv = (T)h.sing[i];
+    h.expl_var[i] = (double)(T)((T)(sv * sv) / (T)nm1);
+  }
+  if (h.opt.center) {
+    h.total_var = h.prep_total_var;
+  } else {  // sparse/mod.rs:218-223
+    h.total_var = 0;
+    for (uint64_t i = 0; i < h.k; ++i) h.total_var += h.expl_var[i];
+  }
+  h.fitted = true;
+  h.timer.stop(total_ev);
+  SAPCA_HIP(hipStreamSynchronize(s));
+  collect_timings(h, true);
+  if (total_ev >= 0) h.timings.fit_total_ms = h.timer.ms(total_ev);
+  {
+    // ALGORITHMIC bytes of one sparse x dense sweep
+    const double l = (double)std::min<uint64_t>(h.opt.n_components + h.opt.n_oversamples,
+                                                std::min<uint64_t>(h.m_global, (uint64_t)n_used));
+    h.timings.bytes_per_sweep = (double)h.a_used.nnz * (sizeof(T) + 4) + ((double)h.a_used.rows + 1) * 8 +
+                                (double)n_used * l * sizeof(T) + (double)h.a_used.rows * l * sizeof(T);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// transform
+// ------------------------------------------------------------------------------------------
+template <typename T>
+void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
+  hipStream_t s = h.stream;
+  const bool masked = !h.mask.empty();
+  if (masked && (int64_t)h.mask.size() != A.cols)  // sparse_masked/mod.rs:440-444
+    throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
+  if (!h.fitted) throw Error(SAPCA_ERR_NOT_FITTED, "Must be fitted before transform!");  // sparse/mod.rs:259,263
+  SAPCA_CHECK(h.dtype == kDtype, SAPCA_ERR_ARG, "transform dtype differs from the fitted model's");
+  SAPCA_CHECK((uint64_t)A.cols == h.n_cols, SAPCA_ERR_ARG, "transform: column count differs from the fitted matrix");
+  SAPCA_CHECK(masked == h.has_mask_maps, SAPCA_ERR_ARG, "transform: mask changed since fit");
+  // keep the fit's spans (their events stay valid); drop those of an earlier transform
+  h.spans.erase(std::remove_if(h.spans.begin(), h.spans.end(), [](const std::pair<int, int>& p) { return p.first == C_TRANSFORM; }),
+                h.spans.end());
+  if (h.spans.empty()) h.timer.begin_collect(s, h.opt.collect_timings != 0);
+  const int64_t m = A.rows, n = A.cols, n_used = (int64_t)h.n_used;
+  const int k = (int)h.k, ldk = (int)round_up(k, 16);
+  const bool center = h.opt.center != 0;
+  const bool ref_sem = h.opt.transform_semantics == SAPCA_TRANSFORM_REFERENCE;
+  if (m == 0) return;
+  {
+    Scope sc(h, C_TRANSFORM);
+    H::PrepKey key;
+    key.ptr = A.ptr; key.idx = A.idx; key.val = A.val; key.m = (uint64_t)m; key.n = (uint64_t)n;
+    key.nnz = (uint64_t)A.nnz; key.mask_version = h.mask_version; key.dtype = kDtype; key.valid = true;
+    const bool prepared = h.prep_key == key;
+    CsrView<T> Au;
+    double* d_cnt = nullptr;
+    if (prepared) {
+      Au = view(h.a_used);
+      d_cnt = h.stats.ptr<double>() + 2 * n;
+    } else if (masked) {
+      h.prep_key.valid = false;  // the compaction buffers are about to be reused
+      std::vector<int32_t> o2m32((size_t)n);
+      for (int64_t j = 0; j < n; ++j) o2m32[(size_t)j] = (int32_t)h.orig_to_masked[(size_t)j];
+      int32_t* d_o2m = h.o2m_dev.as<int32_t>((size_t)n);
+      SAPCA_HIP(hipMemcpyAsync(d_o2m, o2m32.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
+      int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(A.nnz, 1));
+      T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(A.nnz, 1));
+      int64_t nnz_used = 0;
+      k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s);
+      Au.rows = m; Au.cols = n_used; Au.nnz = nnz_used; Au.ptr = ca_ptr; Au.idx = ca_idx; Au.val = ca_val;
+    } else {
+      Au = A;
+      if (ref_sem) {
+        h.prep_key.valid = false;
+        d_cnt = h.stats.as<double>((size_t)3 * n + 1) + 2 * n;
+        k::column_counts_f64(A.idx, A.nnz, n, d_cnt, h.scratch, s);
+        if (h.comm.active()) h.comm.allreduce(d_cnt, (uint64_t)n, 1, s);
+      }
+    }
+    double* small = h.small.as<double>(kSmallDoubles);
+    T* cvec = reinterpret_cast<T*>(small + (size_t)6 * 128 * 128 + 64);
+    const T* mu = h.mean_used_dev.ptr<T>();
+    const T* comps = h.components_dev.ptr<T>();
+    T* W = h.panel_w.as<T>((size_t)n_used * ldk);
+    const bool vec_ok = true;
+    (void)vec_ok;
+    if (ref_sem && !masked) {
+      // Q2 (sparse/mod.rs:268-282): t_ik = sum_j cnt_j (x_ij - [center] mu_j) V_kj
+      k::scaled_transpose(comps, n_used, k, d_cnt, W, ldk, s);
+      if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
+      k::spmm(Au, nullptr, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, s);
+    } else if (ref_sem && masked) {
+      // Q3 (sparse_masked/mod.rs:488-529): mean subtracted at stored, kept entries only
+      k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
+      CsrView<T> As = Au;
+      if (center) {
+        T* sv = h.shifted_val.as<T>((size_t)std::max<int64_t>(Au.nnz, 1));
+        k::subtract_column_mean(Au, mu, sv, s);
+        As.val = sv;
+      }
+      k::spmm(As, nullptr, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, s);
+    } else {
+      // opt-in: the mathematically centred projection (A - 1 mu^T) V^T
+      k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
+      if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
+      k::spmm(Au, nullptr, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, s);
+    }
+  }
+  SAPCA_HIP(hipStreamSynchronize(s));
+  collect_timings(h, false);
+}
+
+template struct Engine<float>;
+template struct Engine<double>;
+
+}  // namespace sapca

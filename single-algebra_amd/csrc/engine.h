@@ -1,0 +1,98 @@
+// The handle behind the C ABI and the typed engine that drives the kernels.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "comm.h"
+#include "common.h"
+#include "kernels.h"
+
+struct sapca_handle_s {
+  sapca_options opt{};
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  // builder state
+  std::vector<uint8_t> mask;
+  uint64_t mask_version = 0;
+  std::vector<double> omega;  // injected test matrix (rows x cols, row-major)
+  size_t omega_rows = 0, omega_cols = 0;
+
+  // fitted state
+  bool fitted = false;
+  int dtype = 0;  // 0 = f32, 1 = f64
+  uint64_t k = 0, n_used = 0, n_cols = 0, m_fit = 0;
+  std::vector<double> sing, expl_var, mean;  // k, k, n_cols
+  double total_var = 0;
+  std::vector<uint64_t> cols_to_use;
+  std::vector<int64_t> orig_to_masked;
+  bool has_mask_maps = false;
+  int chol_regularised = 0;
+
+  // prepared-operator cache key (the matrix the device-side companions were built from)
+  struct PrepKey {
+    const void *ptr = nullptr, *idx = nullptr, *val = nullptr;
+    uint64_t m = 0, n = 0, nnz = 0, mask_version = 0;
+    int dtype = -1;
+    bool valid = false;
+    bool operator==(const PrepKey& o) const {
+      return valid && o.valid && ptr == o.ptr && idx == o.idx && val == o.val && m == o.m && n == o.n && nnz == o.nnz &&
+             mask_version == o.mask_version && dtype == o.dtype;
+    }
+  } prep_key;
+  struct RawCsr {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    const void *ptr = nullptr, *idx = nullptr, *val = nullptr;
+  } a_used, at_used;
+  uint64_t m_global = 0;
+  std::vector<double> prep_mean;  // column means of the prepared matrix (n)
+  double prep_total_var = 0;
+
+  // device buffers (grow-only)
+  sapca::DevBuf in_ptr, in_idx, in_val, up64, out_tmp;           // host-entry uploads
+  sapca::DevBuf at_ptr, at_idx, at_val;                          // A^T
+  sapca::DevBuf ca_ptr, ca_idx, ca_val, cat_ptr, cat_idx, cat_val;  // mask-compacted A, A^T
+  sapca::DevBuf shifted_val;                                     // a_ij - mu_j (quirk Q3 operand)
+  sapca::DevBuf scratch, scratch2;
+  sapca::DevBuf panel_x, panel_y, panel_w;
+  sapca::DevBuf small;                                           // G, R1, R2, Rinv, M, cvec, svec, info
+  sapca::DevBuf stats;                                           // sum, sumsq, cnt (f64, n each)
+  sapca::DevBuf mean_used_dev, o2m_dev, sel_rows_dev;
+  sapca::DevBuf components_dev;                                  // k x n_used, T
+  sapca::DevBuf lanczos_buf;
+  sapca::DevBuf tile_a, tile_at;                                 // tile indices for the LDS sweep
+  sapca::TileIndex tiles_a, tiles_at;
+
+  sapca::EventTimer timer;
+  std::vector<std::pair<int, int>> spans;  // (category, event index) of the last fit/transform
+  sapca_timings timings{};
+  sapca::Comm comm;
+};
+
+namespace sapca {
+
+template <typename T>
+struct Engine {
+  using H = sapca_handle_s;
+  static constexpr int kDtype = sizeof(T) == 8 ? 1 : 0;
+  static void prepare(H& h, const CsrView<T>& A);
+  static void fit(H& h, const CsrView<T>& A);
+  static void transform(H& h, const CsrView<T>& A, T* d_out);
+  static void fit_randomized(H& h);
+  static void fit_lanczos(H& h);
+  // normaliser on a rows x ld panel; R_out (ld x ld f64 device, may be null) receives the
+  // accumulated upper factor of the last CholeskyQR2.
+  static void normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2);
+  static CsrView<T> view(const H::RawCsr& r) {
+    CsrView<T> v;
+    v.rows = r.rows; v.cols = r.cols; v.nnz = r.nnz;
+    v.ptr = static_cast<const int64_t*>(r.ptr);
+    v.idx = static_cast<const int32_t*>(r.idx);
+    v.val = static_cast<const T*>(r.val);
+    return v;
+  }
+};
+
+}  // namespace sapca

@@ -1,0 +1,89 @@
+// Launchers of the hand-written gfx950 kernels.  Everything takes device pointers and a
+// stream; nothing here allocates except through the DevBuf scratch arguments.
+#pragma once
+#include "common.h"
+
+namespace sapca {
+namespace k {
+
+// ---- prep.hip --------------------------------------------------------------------------
+// nalgebra's usize indices -> int64 row offsets + int32 column indices; *flag |= 1 on col >= n.
+void narrow_indices(const uint64_t* ptr64, const uint64_t* idx64, int64_t m, int64_t nnz, int64_t n,
+                    int64_t* ptr, int32_t* idx, int* flag, hipStream_t s);
+// CSR(A) -> CSR(A^T), entries of each A^T row in ascending A-row order (stable, deterministic).
+template <typename T>
+void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s);
+// Row sums of a CSR (applied to A^T: the reference's sum_col / sum_col_squared), f64 accumulation.
+template <typename T>
+void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s);
+// Mask compaction of A: keep entries with o2m[col] >= 0, renumbered.  Two passes around a scan.
+template <typename T>
+void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
+                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s);
+// Row selection of A^T: rows listed in `rows` (ascending), column indices untouched.
+template <typename T>
+void select_rows(const CsrView<T>& At, const int32_t* rows, int64_t n_sel, int64_t* new_ptr, int32_t* new_idx,
+                 T* new_val, int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s);
+// vals_out[e] = vals[e] - mu_full[cols_to_use[idx[e]]]   (quirk Q3 operand)
+template <typename T>
+void subtract_column_mean(const CsrView<T>& A, const T* mu_by_col, T* vals_out, hipStream_t s);
+// out[r] = ptr[r+1] - ptr[r] as f64 (column counts when applied to A^T's row offsets)
+void row_lengths_f64(const int64_t* ptr, int64_t rows, double* out, hipStream_t s);
+// out[j] = number of stored entries with column j (integer atomics; transform of a matrix that
+// was not the fitted one)
+void column_counts_f64(const int32_t* idx, int64_t nnz, int64_t n, double* out, DevBuf& scratch, hipStream_t s);
+// per-row segment table for the LDS-tiled sweep: seg[r][t] = first entry of row r with col >= t*tile_cols
+template <typename T>
+void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* seg, hipStream_t s);
+
+// ---- spmm.hip --------------------------------------------------------------------------
+// Y[r][j] = sum_e val_e X[col_e][j] - cvec[j]   for j < ncols; X has leading dimension ldx
+// (multiple of 16/sizeof(T)... see spmm.hip), Y leading dimension ldy.  cvec may be null.
+template <typename T>
+void spmm(const CsrView<T>& A, const TileIndex* tiles, const T* X, int ldx, T* Y, int ldy, int ncols,
+          const T* cvec, int variant, hipStream_t s);
+
+// ---- dense.hip -------------------------------------------------------------------------
+// G = P^T P (ld x ld, f64, full symmetric) for a rows x ld panel with ld % 16 == 0, ld <= 128.
+template <typename T>
+void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s);
+// Upper Cholesky G = R^T R on the leading l x l block, Rinv = R^{-1}; both ld x ld, zero padded.
+// *info += number of pivots that had to be regularised.
+void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s);
+// out[rows x ldo] = P[rows x ld] * M[ld x ldo]  (M f64, row-major, ldo % 16 == 0); out may alias P
+// when ldo == ld.
+template <typename T>
+void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s);
+// out[j] = sum_r w[r] P[r][j]  (w null => ones), j < ld, f64 accumulation.
+template <typename T>
+void weighted_colsum(const T* P, int64_t rows, int ld, const T* w, T* out, DevBuf& scratch, hipStream_t s);
+// Z[r][j] -= mu[r] * svec[j]
+template <typename T>
+void rank1_subtract(T* Z, int64_t rows, int ld, const T* mu, const T* svec, hipStream_t s);
+// components[r][j] = sign_r * VtT[j][r] for r < k, with sign_r making the largest-|.| entry of
+// row r positive (first index on ties): single_svdlib::randomized::svd_flip, v-based.
+template <typename T>
+void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s);
+// W[j][r] = scale[j] * comps[r][j]  (r < k; zero for k <= r < ld); scale may be null.
+template <typename T>
+void scaled_transpose(const T* comps, int64_t n, int k, const double* scale, T* W, int ld, hipStream_t s);
+template <typename T>
+void fill_zero(T* p, int64_t count, hipStream_t s);
+template <typename T>
+void convert_from_f64(const double* in, T* out, int64_t count, hipStream_t s);
+template <typename T>
+void strip_padding(const T* in, int64_t rows, int ld, int ncols, T* out, hipStream_t s);
+template <typename T>
+void add_padding(const T* in, int64_t rows, int ncols, T* out, int ld, hipStream_t s);
+
+// ---- rng.hip ---------------------------------------------------------------------------
+// Omega[r][j] ~ N(0,1) for j < l (zero for l <= j < ld), a pure function of (seed, r*l+j).
+template <typename T>
+void gaussian_panel(T* out, int64_t rows, int l, int ld, uint32_t seed, hipStream_t s);
+
+// ---- lanczos.hip (BLAS-1/2 helpers on f64 vectors) ---------------------------------------
+template <typename T>
+void spmv(const CsrView<T>& A, const double* x, double* y, hipStream_t s);
+
+}  // namespace k
+}  // namespace sapca

@@ -1,0 +1,364 @@
+// One-time preparation of the device-resident operator: index narrowing, transposition,
+// column statistics, mask compaction, tile index.  None of this is in the sweep loop.
+//
+// Reference semantics restated here:
+//   row_sums on A^T            == <CsrMatrix as MatrixSum>::sum_col / sum_col_squared
+//                                 (src/sparse/csr.rs:259-312, 558-608), f64 accumulation
+//   compact_columns/select_rows == MaskedCSRMatrix::new (call site
+//                                 src/dimred/pca/sparse_masked/mod.rs:313): kept columns
+//                                 renumbered 0..n' in ascending order
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "kernels.h"
+
+namespace sapca {
+namespace k {
+
+namespace {
+
+constexpr int WAVE = 64;
+
+__global__ void narrow_ptr_kernel(const uint64_t* __restrict__ in, int64_t* __restrict__ out, int64_t count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (int64_t)in[i];
+}
+
+__global__ void narrow_idx_kernel(const uint64_t* __restrict__ in, int32_t* __restrict__ out, int64_t count,
+                                  uint64_t n, int* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < count; i += stride) {
+    uint64_t c = in[i];
+    bad |= c >= n;
+    out[i] = (int32_t)c;
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
+// rowid[e] = row owning entry e; one wave per row, grid-stride.
+__global__ void expand_rows_kernel(const int64_t* __restrict__ ptr, int64_t rows, int32_t* __restrict__ rowid) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) rowid[e] = (int32_t)r;
+  }
+}
+
+// ptr[j] = first position in the ascending key array with key >= j, j in [0, nkeys].
+__global__ void lower_bound_kernel(const uint32_t* __restrict__ keys, int64_t count, int64_t nkeys,
+                                   int64_t* __restrict__ ptr) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > nkeys) return;
+  int64_t lo = 0, hi = count;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < j) lo = mid + 1; else hi = mid;
+  }
+  ptr[j] = lo;
+}
+
+template <typename T>
+__global__ void gather_transposed_kernel(const uint32_t* __restrict__ perm, const int32_t* __restrict__ rowid,
+                                         const T* __restrict__ val, int64_t count, int32_t* __restrict__ t_idx,
+                                         T* __restrict__ t_val) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    const uint32_t e = perm[i];
+    t_idx[i] = rowid[e];
+    t_val[i] = val[e];
+  }
+}
+
+template <typename T>
+__global__ void row_sums_kernel(const int64_t* __restrict__ ptr, const T* __restrict__ val, int64_t rows,
+                                double* __restrict__ sum, double* __restrict__ sumsq) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    double a = 0, b = 0;
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) {
+      const double v = (double)val[e];
+      a += v;
+      b += v * v;
+    }
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off);
+      b += __shfl_xor(b, off);
+    }
+    if (lane == 0) {
+      sum[r] = a;
+      if (sumsq) sumsq[r] = b;
+    }
+  }
+}
+
+template <typename T>
+__global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
+                                  const int32_t* __restrict__ o2m, int64_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    int c = 0;
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) c += o2m[idx[e]] >= 0;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) cnt[r] = c;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[rows] = 0;
+}
+
+template <typename T>
+__global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                  const T* __restrict__ val, int64_t rows, const int32_t* __restrict__ o2m,
+                                  const int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_idx,
+                                  T* __restrict__ new_val) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    int64_t out = new_ptr[r];
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    for (int64_t base = e0; base < e1; base += WAVE) {
+      const int64_t e = base + lane;
+      int32_t mi = -1;
+      T v = 0;
+      if (e < e1) {
+        mi = o2m[idx[e]];
+        v = val[e];
+      }
+      const unsigned long long keep = __ballot(mi >= 0);
+      const int before = __popcll(keep & ((1ull << lane) - 1ull));
+      if (mi >= 0) {
+        new_idx[out + before] = mi;
+        new_val[out + before] = v;
+      }
+      out += __popcll(keep);
+    }
+  }
+}
+
+__global__ void selected_lengths_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ rows,
+                                        int64_t n_sel, int64_t* __restrict__ len) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_sel) {
+    const int32_t r = rows[i];
+    len[i] = ptr[r + 1] - ptr[r];
+  } else if (i == n_sel) {
+    len[i] = 0;
+  }
+}
+
+template <typename T>
+__global__ void copy_selected_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                     const T* __restrict__ val, const int32_t* __restrict__ rows, int64_t n_sel,
+                                     const int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_idx,
+                                     T* __restrict__ new_val) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t i = wave; i < n_sel; i += nwaves) {
+    const int32_t r = rows[i];
+    const int64_t src = ptr[r], len = ptr[r + 1] - src, dst = new_ptr[i];
+    for (int64_t t = lane; t < len; t += WAVE) {
+      new_idx[dst + t] = idx[src + t];
+      new_val[dst + t] = val[src + t];
+    }
+  }
+}
+
+template <typename T>
+__global__ void subtract_column_mean_kernel(const int32_t* __restrict__ idx, const T* __restrict__ val,
+                                            int64_t count, const T* __restrict__ mu, T* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) out[i] = val[i] - mu[idx[i]];
+}
+
+// seg[r][t] = number of entries of row r with col < t*tile_cols (t = 0..n_tiles): one lane
+// per (row, boundary) binary search; 64 boundaries of a row share a wave.
+template <typename T>
+__global__ void tile_index_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
+                                  int tile_cols, int n_tiles, int32_t* __restrict__ seg) {
+  const int64_t total = rows * (int64_t)(n_tiles + 1);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t r = i / (n_tiles + 1);
+    const int t = (int)(i - r * (n_tiles + 1));
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    const int64_t bound = (int64_t)t * tile_cols;
+    int64_t lo = e0, hi = e1;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)idx[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    seg[i] = (int32_t)(lo - e0);
+  }
+}
+
+__global__ void ptr_diff_kernel(const int64_t* __restrict__ ptr, int64_t rows, double* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) out[i] = (double)(ptr[i + 1] - ptr[i]);
+}
+
+__global__ void histogram_kernel(const int32_t* __restrict__ idx, int64_t count, unsigned int* __restrict__ hist) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) atomicAdd(&hist[idx[i]], 1u);
+}
+
+__global__ void u32_to_f64_kernel(const unsigned int* __restrict__ in, int64_t count, double* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (double)in[i];
+}
+
+inline int grid_for(int64_t work_items, int block, int cap = 8192) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+inline void exclusive_scan_i64(int64_t* data, int64_t count, DevBuf& scratch, size_t scratch_offset, hipStream_t s) {
+  size_t bytes = 0;
+  SAPCA_HIP(rocprim::exclusive_scan(nullptr, bytes, data, data, (int64_t)0, (size_t)count,
+                                    rocprim::plus<int64_t>(), s));
+  char* base = static_cast<char*>(scratch.ensure(scratch_offset + bytes + 256));
+  SAPCA_HIP(rocprim::exclusive_scan(base + scratch_offset, bytes, data, data, (int64_t)0, (size_t)count,
+                                    rocprim::plus<int64_t>(), s));
+}
+
+}  // namespace
+
+void narrow_indices(const uint64_t* ptr64, const uint64_t* idx64, int64_t m, int64_t nnz, int64_t n, int64_t* ptr,
+                    int32_t* idx, int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(narrow_ptr_kernel, dim3(grid_for(m + 1, 256, 1 << 30)), dim3(256), 0, s, ptr64, ptr, m + 1);
+  if (nnz > 0)
+    hipLaunchKernelGGL(narrow_idx_kernel, dim3(grid_for(nnz, 256, 4096)), dim3(256), 0, s, idx64, idx, nnz,
+                       (uint64_t)n, flag);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s) {
+  const int64_t nnz = A.nnz;
+  SAPCA_CHECK(nnz < (int64_t)0xFFFFFFFFll, SAPCA_ERR_ARG, "more than 2^32-1 stored entries per shard is not supported");
+  if (nnz == 0) {
+    SAPCA_HIP(hipMemsetAsync(t_ptr, 0, (A.cols + 1) * sizeof(int64_t), s));
+    return;
+  }
+  int bits = 1;
+  while ((1ll << bits) < A.cols) ++bits;
+  size_t sort_bytes = 0;
+  rocprim::counting_iterator<uint32_t> iota(0);
+  SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, iota,
+                                      (uint32_t*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
+  const size_t a = (size_t)round_up(nnz * 4, 256);
+  char* base = static_cast<char*>(scratch.ensure(3 * a + sort_bytes + 256));
+  int32_t* rowid = reinterpret_cast<int32_t*>(base);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + a);
+  uint32_t* perm = reinterpret_cast<uint32_t*>(base + 2 * a);
+  void* tmp = base + 3 * a;
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.rows, rowid);
+  SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, reinterpret_cast<const uint32_t*>(A.idx), keys_out, iota, perm,
+                                      (size_t)nnz, 0u, (unsigned)bits, s));
+  hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out, nnz,
+                     A.cols, t_ptr);
+  hipLaunchKernelGGL((gather_transposed_kernel<T>), dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, perm, rowid,
+                     A.val, nnz, t_idx, t_val);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s) {
+  if (At.rows == 0) return;
+  hipLaunchKernelGGL((row_sums_kernel<T>), dim3(grid_for(At.rows * WAVE, 256, 4096)), dim3(256), 0, s, At.ptr, At.val,
+                     At.rows, sum, sumsq);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
+                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s) {
+  const int g = grid_for(A.rows * WAVE, 256, 4096);
+  hipLaunchKernelGGL((count_kept_kernel<T>), dim3(g), dim3(256), 0, s, A.ptr, A.idx, A.rows, o2m, new_ptr);
+  exclusive_scan_i64(new_ptr, A.rows + 1, scratch, 0, s);
+  hipLaunchKernelGGL((write_kept_kernel<T>), dim3(g), dim3(256), 0, s, A.ptr, A.idx, A.val, A.rows, o2m, new_ptr,
+                     new_idx, new_val);
+  SAPCA_HIP(hipGetLastError());
+  SAPCA_HIP(hipMemcpyAsync(new_nnz_host, new_ptr + A.rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SAPCA_HIP(hipStreamSynchronize(s));
+}
+
+template <typename T>
+void select_rows(const CsrView<T>& At, const int32_t* rows, int64_t n_sel, int64_t* new_ptr, int32_t* new_idx,
+                 T* new_val, int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s) {
+  hipLaunchKernelGGL(selected_lengths_kernel, dim3(grid_for(n_sel + 1, 256, 1 << 30)), dim3(256), 0, s, At.ptr, rows,
+                     n_sel, new_ptr);
+  exclusive_scan_i64(new_ptr, n_sel + 1, scratch, 0, s);
+  if (n_sel > 0)
+    hipLaunchKernelGGL((copy_selected_kernel<T>), dim3(grid_for(n_sel * WAVE, 256, 4096)), dim3(256), 0, s, At.ptr,
+                       At.idx, At.val, rows, n_sel, new_ptr, new_idx, new_val);
+  SAPCA_HIP(hipGetLastError());
+  SAPCA_HIP(hipMemcpyAsync(new_nnz_host, new_ptr + n_sel, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SAPCA_HIP(hipStreamSynchronize(s));
+}
+
+template <typename T>
+void subtract_column_mean(const CsrView<T>& A, const T* mu_by_col, T* vals_out, hipStream_t s) {
+  if (A.nnz == 0) return;
+  hipLaunchKernelGGL((subtract_column_mean_kernel<T>), dim3(grid_for(A.nnz, 256, 8192)), dim3(256), 0, s, A.idx, A.val,
+                     A.nnz, mu_by_col, vals_out);
+  SAPCA_HIP(hipGetLastError());
+}
+
+void row_lengths_f64(const int64_t* ptr, int64_t rows, double* out, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(ptr_diff_kernel, dim3(grid_for(rows, 256, 1 << 30)), dim3(256), 0, s, ptr, rows, out);
+  SAPCA_HIP(hipGetLastError());
+}
+
+void column_counts_f64(const int32_t* idx, int64_t nnz, int64_t n, double* out, DevBuf& scratch, hipStream_t s) {
+  if (n == 0) return;
+  unsigned int* hist = scratch.as<unsigned int>((size_t)n);
+  SAPCA_HIP(hipMemsetAsync(hist, 0, (size_t)n * sizeof(unsigned int), s));
+  if (nnz > 0) hipLaunchKernelGGL(histogram_kernel, dim3(grid_for(nnz, 256, 4096)), dim3(256), 0, s, idx, nnz, hist);
+  hipLaunchKernelGGL(u32_to_f64_kernel, dim3(grid_for(n, 256, 1 << 30)), dim3(256), 0, s, hist, n, out);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* seg, hipStream_t s) {
+  if (A.rows == 0) return;
+  hipLaunchKernelGGL((tile_index_kernel<T>), dim3(grid_for(A.rows * (int64_t)(n_tiles + 1), 256, 16384)), dim3(256), 0,
+                     s, A.ptr, A.idx, A.rows, tile_cols, n_tiles, seg);
+  SAPCA_HIP(hipGetLastError());
+}
+
+#define INSTANTIATE(T)                                                                                              \
+  template void transpose_csr<T>(const CsrView<T>&, int64_t*, int32_t*, T*, DevBuf&, hipStream_t);                  \
+  template void row_sums<T>(const CsrView<T>&, double*, double*, hipStream_t);                                      \
+  template void compact_columns<T>(const CsrView<T>&, const int32_t*, int64_t*, int32_t*, T*, int64_t*, DevBuf&,    \
+                                   hipStream_t);                                                                    \
+  template void select_rows<T>(const CsrView<T>&, const int32_t*, int64_t, int64_t*, int32_t*, T*, int64_t*,        \
+                               DevBuf&, hipStream_t);                                                               \
+  template void subtract_column_mean<T>(const CsrView<T>&, const T*, T*, hipStream_t);                              \
+  template void build_tile_index<T>(const CsrView<T>&, int, int, int32_t*, hipStream_t);
+INSTANTIATE(float)
+INSTANTIATE(double)
+#undef INSTANTIATE
+
+}  // namespace k
+}  // namespace sapca

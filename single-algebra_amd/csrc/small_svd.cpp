@@ -1,0 +1,125 @@
+#include "small_svd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace sapca {
+
+void jacobi_svd(const std::vector<double>& A, int l, std::vector<double>& U, std::vector<double>& s) {
+  // Work on columns of W = A (stored column-major for stride-1 rotations): A V = W, W -> U diag(s).
+  std::vector<double> W((size_t)l * l);
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < l; ++j) W[(size_t)j * l + i] = A[(size_t)i * l + j];
+  for (int sweep = 0; sweep < 80; ++sweep) {
+    double off = 0;
+    for (int p = 0; p + 1 < l; ++p) {
+      double* wp = &W[(size_t)p * l];
+      for (int q = p + 1; q < l; ++q) {
+        double* wq = &W[(size_t)q * l];
+        double a = 0, b = 0, g = 0;
+        for (int i = 0; i < l; ++i) {
+          a += wp[i] * wp[i];
+          b += wq[i] * wq[i];
+          g += wp[i] * wq[i];
+        }
+        if (a == 0 || b == 0) continue;
+        const double r = std::fabs(g) / std::sqrt(a * b);
+        off = std::max(off, r);
+        if (r < 1e-16) continue;
+        const double zeta = (b - a) / (2.0 * g);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < l; ++i) {
+          const double x = wp[i], y = wq[i];
+          wp[i] = cs * x - sn * y;
+          wq[i] = sn * x + cs * y;
+        }
+      }
+    }
+    if (off < 1e-15) break;
+  }
+  std::vector<double> norm(l);
+  for (int j = 0; j < l; ++j) {
+    double a = 0;
+    for (int i = 0; i < l; ++i) a += W[(size_t)j * l + i] * W[(size_t)j * l + i];
+    norm[j] = std::sqrt(a);
+  }
+  std::vector<int> order(l);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return norm[x] > norm[y]; });
+  U.assign((size_t)l * l, 0.0);
+  s.assign(l, 0.0);
+  for (int c = 0; c < l; ++c) {
+    const int j = order[c];
+    s[c] = norm[j];
+    if (norm[j] > 0)
+      for (int i = 0; i < l; ++i) U[(size_t)i * l + c] = W[(size_t)j * l + i] / norm[j];
+  }
+}
+
+bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z) {
+  // Implicit QL with Wilkinson shifts (EISPACK tql2 structure).  e[i] couples (i-1, i), e[0] unused.
+  Z.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) Z[(size_t)i * n + i] = 1.0;
+  if (n == 0) return true;
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 200) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = Z[(size_t)k * n + i + 1];
+            Z[(size_t)k * n + i + 1] = s * Z[(size_t)k * n + i] + c * f;
+            Z[(size_t)k * n + i] = c * Z[(size_t)k * n + i] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  // sort ascending
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
+  std::vector<double> d2(n), Z2((size_t)n * n);
+  for (int c = 0; c < n; ++c) {
+    d2[c] = d[order[c]];
+    for (int k = 0; k < n; ++k) Z2[(size_t)k * n + c] = Z[(size_t)k * n + order[c]];
+  }
+  d.swap(d2);
+  Z.swap(Z2);
+  return true;
+}
+
+}  // namespace sapca

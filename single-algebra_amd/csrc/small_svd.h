@@ -1,0 +1,17 @@
+// Host-side f64 factorisations of the l x l cores (l <= 128): nothing here touches the m- or
+// n-sized data, which stays on the GPU.
+#pragma once
+#include <vector>
+
+namespace sapca {
+
+// One-sided Jacobi (Hestenes) SVD of the row-major l x l matrix A = U diag(s) V^T.
+// Returns s sorted descending and the matching columns of U (row-major l x l).
+void jacobi_svd(const std::vector<double>& A, int l, std::vector<double>& U, std::vector<double>& s);
+
+// Symmetric tridiagonal eigen-decomposition (implicit QL): d diagonal, e sub-diagonal (e[0] unused
+// convention: e[i] couples i-1 and i).  On return d holds eigenvalues (ascending) and Z (row-major
+// n x n) the eigenvectors in columns.  Returns false if it failed to converge.
+bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z);
+
+}  // namespace sapca

@@ -1,0 +1,99 @@
+"""ctypes binding of libsapca.so (include/sapca.h).  No fallbacks: if the HIP library is
+missing or there is no GPU, calls fail loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libsapca.so"))
+
+OK, ERR_ARG, ERR_MASK_LEN, ERR_NOT_FITTED, ERR_SVD, ERR_HIP, ERR_COMM, ERR_NOMEM = range(8)
+LANCZOS, RANDOM = 0, 1
+NORM_QR, NORM_LU, NORM_NONE = 0, 1, 2
+TRANSFORM_REFERENCE, TRANSFORM_CENTERED = 0, 1
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("random_seed", C.c_uint32), ("n_components", C.c_uint64),
+        ("alpha", C.c_double), ("tolerance", C.c_double),
+        ("center", C.c_uint8), ("verbose", C.c_uint8), ("collect_timings", C.c_uint8), ("reserved0", C.c_uint8),
+        ("method", C.c_int32), ("n_oversamples", C.c_uint64), ("n_power_iterations", C.c_uint64),
+        ("normalizer", C.c_int32), ("transform_semantics", C.c_int32), ("device_id", C.c_int32),
+        ("spmm_variant", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [
+        ("upload_ms", C.c_double), ("prepare_ms", C.c_double), ("stats_ms", C.c_double),
+        ("spmm_ms", C.c_double), ("spmmt_ms", C.c_double), ("ortho_ms", C.c_double),
+        ("small_svd_ms", C.c_double), ("lanczos_ms", C.c_double), ("transform_ms", C.c_double),
+        ("comm_ms", C.c_double), ("fit_total_ms", C.c_double),
+        ("n_spmm", C.c_uint32), ("n_spmmt", C.c_uint32),
+        ("spmm_sweep_ms", C.c_double * 32), ("spmmt_sweep_ms", C.c_double * 32),
+        ("bytes_per_sweep", C.c_double), ("lanczos_steps", C.c_uint64),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+
+# every symbol include/sapca.h declares (the CPU test checks the library exports each one)
+_TYPED = [
+    "sapca_set_omega", "sapca_fit_csr", "sapca_transform_csr", "sapca_fit_transform_csr",
+    "sapca_fit_csr_device", "sapca_transform_csr_device", "sapca_fit_transform_csr_device",
+    "sapca_get_components", "sapca_get_singular_values", "sapca_get_explained_variance", "sapca_get_mean",
+    "sapca_get_explained_variance_ratio", "sapca_get_cumulative_explained_variance_ratio",
+    "sapca_get_feature_importances", "sapca_colstats_csr", "sapca_spmm_csr", "sapca_spmmt_csr",
+    "sapca_normalize_panel", "sapca_generate_omega",
+]
+_PLAIN = [
+    "sapca_options_default", "sapca_abi_version", "sapca_create", "sapca_destroy", "sapca_last_error",
+    "sapca_set_mask", "sapca_get_dims", "sapca_get_total_variance", "sapca_get_mask_index_maps",
+    "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_init_rank",
+    "sapca_comm_set_callback", "sapca_comm_allreduce",
+]
+EXPORTED_SYMBOLS = _PLAIN + [f"{n}_{s}" for n in _TYPED for s in ("f32", "f64")]
+
+_lib = None
+
+
+class SapcaError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def load():
+    """dlopen libsapca.so.  torch (if it is going to be used at all) must be imported first so the
+    process shares ONE HIP runtime / RCCL: bench.py and the tests import torch at the top."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C single-algebra_amd` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.sapca_last_error.restype = C.c_char_p
+    lib.sapca_last_error.argtypes = [C.c_void_p]
+    lib.sapca_create.argtypes = [C.POINTER(Options), C.POINTER(C.c_void_p)]
+    lib.sapca_destroy.argtypes = [C.c_void_p]
+    lib.sapca_destroy.restype = None
+    lib.sapca_options_default.argtypes = [C.POINTER(Options)]
+    lib.sapca_options_default.restype = None
+    _lib = lib
+    return lib
+
+
+def default_options() -> Options:
+    o = Options()
+    load().sapca_options_default(C.byref(o))
+    return o
+
+
+def check(handle, status):
+    if status != OK:
+        msg = load().sapca_last_error(handle)
+        raise SapcaError(status, (msg or b"").decode() or f"sapca status {status}")

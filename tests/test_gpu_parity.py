@@ -1,0 +1,321 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the committed
+golden vectors and the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for the mask index maps; f64 within 1e-10-ish of the golden
+vectors; f32 within 1e-4 relative / 1e-4 rad subspace angle (the north-star tolerance)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import sapca
+import sapca_oracle as O
+from sapca import _lib as L
+from sapca import ops, synth
+from sapca import PowerIterationNormalizer as PIN
+from sapca import SVDMethod
+
+pytestmark = pytest.mark.gpu
+
+
+def csr_np(t):
+    p, i, v = t
+    return p.cpu().numpy().astype(np.int64), i.cpu().numpy().astype(np.int64), v.cpu().numpy()
+
+
+def mat(ptr, idx, val, m, n):
+    return sp.csr_matrix((val, idx, ptr), shape=(m, n))
+
+
+@pytest.fixture(scope="module")
+def session():
+    return ops.Session()
+
+
+# ------------------------------------------------------------------ reference-held pins + G1
+def test_ref_pins_sum_col(golden, session):
+    g = golden("ref_pins.npz")
+    A = sp.csr_matrix(g["csc_dense"])
+    s, sq, cnt = session.colstats(A.indptr, A.indices, A.data, 3, 3)
+    assert s.tolist() == [5.0, 3.0, 7.0]                      # csc.rs:1128-1129
+    B = sp.csr_matrix(g["csr_dense"])
+    s, sq, cnt = session.colstats(B.indptr, B.indices, B.data, 4, 3)
+    assert cnt.tolist() == [2, 2, 2]                          # csr.rs:1410-1412
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 2e-6)])
+def test_g1_colstats(golden, session, dtype, tol):
+    g = golden("g1_colstats.npz")
+    s, sq, cnt = session.colstats(g["indptr"], g["indices"], g["data"].astype(dtype), int(g["m"]), int(g["n"]))
+    np.testing.assert_allclose(s, g["sum_col"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(sq, g["sum_col_sq"], rtol=tol, atol=tol)
+    assert cnt.tolist() == g["cnt"].tolist()
+
+
+def test_colstats_large_matches_oracle(session):
+    ptr, idx, val = csr_np(synth.flat_csr(3000, 1000, 0.1, seed=3, dtype=torch.float64))
+    s, sq, cnt = session.colstats(ptr, idx, val, 3000, 1000)
+    np.testing.assert_allclose(s, O.sum_col(ptr, idx, val, 1000), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sq, O.sum_col_squared(ptr, idx, val, 1000), rtol=1e-12)
+    assert np.array_equal(cnt.astype(np.int64), O.nonzero_col(idx, 1000))
+
+
+# ------------------------------------------------------------------ G2: bit-exact integers
+def test_g2_mask_maps_bit_exact(golden):
+    g = golden("g2_masks.npz")
+    for name in ("all_true", "alternating", "head_tail", "bernoulli60_seed7"):
+        est = sapca.MaskedSparsePCABuilder.new().mask(g[name + "_mask"]).build()
+        cols, o2m = est.mask_index_maps()
+        assert cols.dtype == np.uint64 and o2m.dtype == np.int64
+        assert np.array_equal(cols, g[name + "_cols_to_use"])
+        assert np.array_equal(o2m, g[name + "_orig_to_masked"])
+
+
+# ------------------------------------------------------------------ G3: the two sweeps
+@pytest.mark.parametrize("l", [8, 30, 64])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-4)])
+def test_g3_spmm(golden, session, l, dtype, tol):
+    g = golden("g3_spmm.npz")
+    ptr, idx, val = g["indptr"], g["indices"], g["data"].astype(dtype)
+    m, n, mu = int(g["m"]), int(g["n"]), g["mu"].astype(dtype)
+    X, Yin = g[f"X{l}"].astype(dtype), g[f"Yin{l}"].astype(dtype)
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, m, n, X), g[f"AX{l}"], atol=tol * 10)
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, m, n, X, mu), g[f"AcX{l}"], atol=tol * 10)
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, m, n, Yin, None, transposed=True), g[f"AtY{l}"], atol=tol * 10)
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, m, n, Yin, mu, transposed=True), g[f"ActY{l}"], atol=tol * 10)
+
+
+@pytest.mark.parametrize("l", [110, 128])
+def test_spmm_wide_panels(session, l):
+    ptr, idx, val = csr_np(synth.flat_csr(700, 300, 0.05, seed=4, dtype=torch.float32))
+    X = synth.gaussian_panel(300, l, 1).numpy().astype(np.float32)
+    want = mat(ptr, idx, val, 700, 300).astype(np.float64) @ X.astype(np.float64)
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, 700, 300, X), want, atol=2e-3)
+
+
+def test_spmm_edge_rows(session):
+    """empty matrix rows, an all-empty matrix, a single dense row"""
+    ptr = np.array([0, 0, 0, 5, 5], dtype=np.int64)
+    idx = np.array([0, 1, 2, 3, 4], dtype=np.int64)
+    val = np.arange(1, 6, dtype=np.float64)
+    X = np.arange(5 * 3, dtype=np.float64).reshape(5, 3)
+    got = session.spmm(ptr, idx, val, 4, 5, X)
+    want = mat(ptr, idx, val, 4, 5) @ X
+    np.testing.assert_allclose(got, want, atol=1e-12)
+    z = session.spmm(np.zeros(4, np.int64), np.zeros(0, np.int64), np.zeros(0), 3, 5, X)
+    assert np.all(z == 0) and z.shape == (3, 3)
+
+
+# ------------------------------------------------------------------ normaliser (R10)
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 5e-6)])
+def test_normalizer_qr_orthonormal_same_span(session, dtype, tol):
+    P = synth.gaussian_panel(5000, 30, 3).numpy()
+    P[:, 5] = P[:, 4] * (1 + 1e-3) + 1e-3 * P[:, 5]           # ill-conditioned on purpose (cond ~ 1e3)
+    P = P.astype(dtype)
+    Q = session.normalize_panel(P, PIN.QR)
+    np.testing.assert_allclose(Q.T.astype(np.float64) @ Q.astype(np.float64), np.eye(30), atol=tol * 20)
+    q_ref, _ = np.linalg.qr(P.astype(np.float64))
+    assert O.subspace_angle(Q.T, q_ref.T) < (1e-9 if dtype == np.float64 else 2e-3)
+    Lp = session.normalize_panel(P, PIN.LU)
+    assert O.subspace_angle(Lp.T, q_ref.T) < (1e-9 if dtype == np.float64 else 2e-3)
+    assert np.array_equal(session.normalize_panel(P, PIN.NONE), P)
+
+
+def test_omega_generator_matches_host_function(session):
+    om = session.generate_omega(300, 30)
+    np.testing.assert_allclose(om, synth.gaussian_panel(300, 30, 42).numpy(), atol=1e-12)
+    assert abs(om.mean()) < 0.05 and abs(om.std() - 1) < 0.05
+
+
+# ------------------------------------------------------------------ G4: full randomized fit
+def _builder(k, p, q, norm=PIN.QR, **kw):
+    b = sapca.SparsePCABuilder.new().n_components(k).random_seed(42).svd_method(SVDMethod.Random(p, q, norm))
+    for key, v in kw.items():
+        getattr(b, key)(v)
+    return b
+
+
+@pytest.mark.parametrize("dtype,srel,ang,vabs", [(np.float64, 1e-10, 1e-9, 1e-8), (np.float32, 1e-4, 1e-4, 5e-4)])
+def test_g4_randomized_fit_injected_omega(golden, dtype, srel, ang, vabs):
+    g = golden("g4_randomized_fit.npz")
+    m, n, k, p, q = (int(g[x]) for x in "mnkpq")
+    A = mat(g["indptr"], g["indices"], g["data"].astype(dtype), m, n)
+    pca = _builder(k, p, q).build().set_omega(g["omega"])
+    pca.fit(A)
+    np.testing.assert_allclose(pca.mean_(np.float64), g["mean"], atol=1e-13 if dtype == np.float64 else 1e-7)
+    np.testing.assert_allclose(pca.singular_values_(np.float64), g["s"], rtol=srel)
+    assert O.subspace_angle(pca.components_(np.float64), g["vt"]) < ang
+    np.testing.assert_allclose(pca.components_(np.float64), g["vt"], atol=vabs)          # signs: svd_flip
+    np.testing.assert_allclose(pca.explained_variance_(np.float64), g["ev"], rtol=2 * srel)
+    np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), g["ratio"], rtol=2 * srel, atol=1e-7)
+    np.testing.assert_allclose(pca.cumulative_explained_variance_ratio(np.float64), g["cum"], rtol=2 * srel, atol=1e-6)
+    np.testing.assert_allclose(pca.feature_importances(np.float64), g["vt"] ** 2, atol=vabs)
+    assert pca.components_().dtype == dtype and pca.components_().shape == (k, n)
+    # uncentred
+    pca2 = _builder(k, p, q, center=False).build().set_omega(g["omega"])
+    pca2.fit(A)
+    np.testing.assert_allclose(pca2.singular_values_(np.float64), g["s_uncentred"], rtol=srel)
+    assert O.subspace_angle(pca2.components_(np.float64), g["vt_uncentred"]) < ang
+    assert np.all(pca2.mean_() == 0)
+    np.testing.assert_allclose(pca2.total_variance_(), pca2.explained_variance_(np.float64).sum(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("norm", [PIN.LU, PIN.NONE])
+def test_g4_other_normalizers(golden, norm):
+    g = golden("g4_randomized_fit.npz")
+    m, n, k, p, q = (int(g[x]) for x in "mnkpq")
+    A = mat(g["indptr"], g["indices"], g["data"], m, n)
+    pca = _builder(k, p, q, norm).build().set_omega(g["omega"])
+    pca.fit(A)
+    np.testing.assert_allclose(pca.singular_values_(), g["s"], rtol=1e-7)
+    assert O.subspace_angle(pca.components_(), g["vt"]) < 1e-6
+
+
+def test_fit_with_builtin_omega_converges_to_exact(golden):
+    g = golden("g5_gapped_c1.npz")
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    ptr, idx, val = synth.gapped_csr(m, n, float(g["density"]), k, seed=int(g["seed"]), dtype=torch.float32, device="cuda")
+    assert val.numel() == int(g["nnz"])
+    x = sapca.DeviceCsr(ptr, idx, val, (m, n))
+    pca = _builder(k, 10, 4).build()
+    t = pca.fit_transform(x)
+    assert t.shape == (m, k) and t.is_cuda
+    assert O.subspace_angle(pca.components_(np.float64), g["exact_vt"]) < 1e-4           # north-star tolerance
+    np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), g["ratio"], atol=1e-5)
+    np.testing.assert_allclose(pca.singular_values_(np.float64), g["exact_s"][:k], rtol=1e-4)
+
+
+# ------------------------------------------------------------------ G5 vs oracle, device entry points
+@pytest.mark.parametrize("dtype,ang", [(torch.float64, 1e-8), (torch.float32, 1e-4)])
+def test_g5_c1_device_path_vs_oracle(golden, dtype, ang):
+    g = golden("g5_gapped_c1.npz")
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    dev = synth.gapped_csr(m, n, float(g["density"]), k, seed=int(g["seed"]), dtype=dtype, device="cuda")
+    ptr, idx, val = csr_np(dev)
+    om = synth.gaussian_panel(n, k + 10, 42).numpy()
+    want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=10, n_power_iterations=4, omega=om)
+    pca = _builder(k, 10, 4).build().set_omega(om)
+    pca.fit(sapca.DeviceCsr(*dev, (m, n)))
+    assert O.subspace_angle(pca.components_(np.float64), want.components) < ang
+    np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), O.explained_variance_ratio(want.explained_variance),
+                               atol=1e-6)
+    assert O.subspace_angle(pca.components_(np.float64), g["exact_vt"]) < 1e-4
+
+
+# ------------------------------------------------------------------ G7: transform semantics
+@pytest.mark.parametrize("center", [True, False])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 2e-3)])
+def test_g7_transform_reference_semantics(golden, center, dtype, tol):
+    """Fit on the fixture matrix, then check transform against the oracle's restatement of Q2/Q3
+    evaluated with the FITTED components/mean (the fixture's brute-force loops pin the oracle)."""
+    g = golden("g7_transform.npz")
+    m, n = int(g["m"]), int(g["n"])
+    ptr, idx, val = g["indptr"], g["indices"], g["data"].astype(dtype)
+    A = mat(ptr, idx, val, m, n)
+    k = 5
+    pca = _builder(k, 5, 2, center=center).build()
+    t = pca.fit_transform(A)
+    comps, mean = pca.components_(np.float64), pca.mean_(np.float64)
+    want = O.transform_sparse(ptr, idx, val.astype(np.float64), m, n, comps, mean, center)      # Q2
+    np.testing.assert_allclose(t, want, atol=tol * max(1.0, np.abs(want).max()))
+    t_again = pca.transform(A)                                                                  # separate call, re-upload
+    np.testing.assert_allclose(t_again, t, atol=tol * max(1.0, np.abs(want).max()))
+    mpca = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(g["mask"]).center(center)
+            .svd_method(SVDMethod.Random(5, 2, PIN.QR)).build())
+    tm = mpca.fit_transform(A)
+    want_m = O.transform_masked(ptr, idx, val.astype(np.float64), m, n, mpca.components_(np.float64),
+                                mpca.mean_(np.float64), center, g["mask"])                       # Q3
+    np.testing.assert_allclose(tm, want_m, atol=tol * max(1.0, np.abs(want_m).max()))
+    assert mpca.components_().shape == (k, int(g["mask"].sum())) and mpca.mean_().shape == (n,)
+    np.testing.assert_allclose(mpca.transform(A), tm, atol=tol * max(1.0, np.abs(want_m).max()))
+
+
+def test_transform_centered_semantics_opt_in(golden):
+    g = golden("g7_transform.npz")
+    m, n = int(g["m"]), int(g["n"])
+    A = mat(g["indptr"], g["indices"], g["data"], m, n)
+    pca = _builder(5, 5, 2).transform_semantics(L.TRANSFORM_CENTERED).build()
+    t = pca.fit_transform(A)
+    want = (A.toarray() - pca.mean_()[None, :]) @ pca.components_().T
+    np.testing.assert_allclose(t, want, atol=1e-9)
+
+
+# ------------------------------------------------------------------ masked fit
+@pytest.mark.parametrize("dtype,ang", [(np.float64, 1e-8), (np.float32, 1e-4)])
+def test_masked_randomized_fit_vs_oracle(dtype, ang):
+    m, n, k = 4000, 900, 8
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.06, k, seed=21, dtype=torch.float64))
+    mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
+    n_used = int(mask.sum())
+    om = synth.gaussian_panel(n_used, k + 8, 5).numpy()
+    want = O.fit(ptr, idx, val, m, n, n_components=k, n_oversamples=8, n_power_iterations=3, omega=om, mask=mask)
+    est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask)
+           .svd_method(SVDMethod.Random(8, 3, PIN.QR)).build().set_omega(om))
+    est.fit(mat(ptr, idx, val.astype(dtype), m, n))
+    assert est.components_().shape == (k, n_used)
+    assert O.subspace_angle(est.components_(np.float64), want.components) < ang
+    np.testing.assert_allclose(est.singular_values_(np.float64), want.singular_values, rtol=1e-9 if dtype == np.float64 else 1e-4)
+    np.testing.assert_allclose(est.mean_(np.float64), want.mean, atol=1e-12 if dtype == np.float64 else 1e-6)   # FULL width
+    np.testing.assert_allclose(est.total_variance_(), want.total_var, rtol=1e-9 if dtype == np.float64 else 1e-4)
+    cols, o2m = est.mask_index_maps()
+    assert np.array_equal(cols, want.cols_to_use) and np.array_equal(o2m, want.orig_to_masked)
+
+
+# ------------------------------------------------------------------ errors (reference messages)
+def test_error_behaviour():
+    ptr, idx, val = csr_np(synth.flat_csr(50, 20, 0.3, dtype=torch.float64))
+    A = mat(ptr, idx, val, 50, 20)
+    pca = _builder(3, 3, 1).build()
+    with pytest.raises(L.SapcaError, match="Must be fitted before transform!") as e:
+        pca.transform(A)
+    assert e.value.status == L.ERR_NOT_FITTED
+    with pytest.raises(L.SapcaError, match="Model must be fitted first!"):
+        pca.explained_variance_ratio()
+    with pytest.raises(L.SapcaError, match="Model must be fitted first!"):
+        pca.feature_importances()
+    for bad in (np.ones(19, bool), np.zeros(0, bool)):
+        mp = sapca.MaskedSparsePCABuilder.new().n_components(3).mask(bad).svd_method(SVDMethod.Random(3, 1)).build()
+        with pytest.raises(L.SapcaError, match="mask vector length") as e:
+            mp.fit(A)
+        assert e.value.status == L.ERR_MASK_LEN
+    big = _builder(30, 3, 1).build()                       # k > min(m, n): the reference would panic on s[i]
+    with pytest.raises(L.SapcaError, match="Randomized SVD computation failed") as e:
+        big.fit(A)
+    assert e.value.status == L.ERR_SVD
+    none = sapca.MaskedSparsePCABuilder.new().n_components(2).mask(np.zeros(20, bool)).svd_method(SVDMethod.Random(3, 1)).build()
+    with pytest.raises(L.SapcaError) as e:
+        none.fit(A)
+    assert e.value.status == L.ERR_SVD
+
+
+def test_explained_variance_ratio_sums_to_one_q4():
+    ptr, idx, val = csr_np(synth.gapped_csr(2000, 500, 0.08, 6, seed=3, dtype=torch.float32))
+    pca = _builder(6, 6, 2).build()
+    pca.fit(mat(ptr, idx, val, 2000, 500))
+    r = pca.explained_variance_ratio()
+    assert abs(float(r.sum()) - 1.0) < 1e-5 and np.all(np.diff(r) <= 1e-7)
+    np.testing.assert_allclose(pca.cumulative_explained_variance_ratio()[-1], 1.0, atol=1e-5)
+
+
+# ------------------------------------------------------------------ size-independent properties at a larger size
+def test_properties_at_scale():
+    """200k x 4k f32 (2.4e7 stored entries): linearity of the sweeps in the panel, orthonormality of the
+    components, fit_transform == fit + transform, determinism."""
+    m, n, k = 200_000, 4_000, 16
+    dev = synth.gapped_csr(m, n, 0.03, k, seed=42, dtype=torch.float32, device="cuda")
+    x = sapca.DeviceCsr(*dev, (m, n))
+    pca = _builder(k, 8, 2).build()
+    t1 = pca.fit_transform(x)
+    c1 = pca.components_(np.float64)
+    np.testing.assert_allclose(c1 @ c1.T, np.eye(k), atol=5e-5)
+    t2 = pca.transform(x)
+    assert torch.equal(t1, t2)
+    pca_b = _builder(k, 8, 2).build()
+    t3 = pca_b.fit_transform(x)
+    assert torch.equal(t1, t3) and np.array_equal(pca_b.components_(), pca.components_())      # bitwise reproducible
+    ev = pca.explained_variance_(np.float64)
+    assert np.all(np.diff(ev) <= 0) and abs(pca.explained_variance_ratio(np.float64).sum() - 1) < 1e-5
+    # the CENTERED projection of the data onto orthonormal components has variance == explained variance
+    pc = _builder(k, 8, 2).transform_semantics(L.TRANSFORM_CENTERED).build()
+    tc = pc.fit_transform(x).double()
+    np.testing.assert_allclose((tc ** 2).sum(0).cpu().numpy() / (m - 1), pc.explained_variance_(np.float64), rtol=2e-3)
