@@ -50,7 +50,12 @@ def cpu_baseline(name, n, density, k, p, q, seed, gen_device="cpu"):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     from sapca import synth
-    ms = 20000 if name != "small" else 5000
+    ms = 10000 if name != "small" else 5000
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    orc.set_num_threads(min(share, 16))      # a 1-GPU box gives this job 16 host cores
     ptr, idx, val = synth.gapped_csr(ms, n, density, k, seed=seed, dtype=torch.float32, device=gen_device, chunk_elems=1 << 24)
     ptr, idx, val = ptr.cpu().numpy(), idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
     om = synth.gaussian_panel(n, k + p, 42).numpy().astype(np.float32)

@@ -31,6 +31,14 @@
 #define PARALLEL_THRESHOLD 200000 /* csr.rs:19 */
 #define RAYON_CHUNK 8192          /* csr.rs:289, 585 */
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -47,6 +47,10 @@ def num_threads():
     return int(lib().orc_num_threads())
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
 def sum_col(indices, data, n, squared=False):
     suf, ct = _suf(data.dtype)
     out = np.zeros(n, dtype=data.dtype)

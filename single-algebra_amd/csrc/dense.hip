@@ -73,12 +73,23 @@ gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ 
   for (int i = threadIdx.x; i < NPAIR * 256; i += blockDim.x) slab[i] = lds[i];
 }
 
-__global__ void gram_reduce_kernel(const double* __restrict__ slabs, int nslabs, int nt, int ld, double* __restrict__ G) {
+// 16 elements x 16 slab-groups per block; each group sums its slabs in order, the 16 group sums
+// are added in order: a fixed reduction tree, bitwise reproducible.
+__global__ void __launch_bounds__(256)
+gram_reduce_kernel(const double* __restrict__ slabs, int nslabs, int nt, int ld, double* __restrict__ G) {
+  __shared__ double part[16][17];
   const int npair = nt * (nt + 1) / 2;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npair * 256) return;
+  const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;
   double sum = 0;
-  for (int b = 0; b < nslabs; ++b) sum += slabs[(int64_t)b * npair * 256 + i];
+  if (i < npair * 256)
+    for (int b = grp; b < nslabs; b += 16) sum += slabs[(int64_t)b * npair * 256 + i];
+  part[grp][e] = sum;
+  __syncthreads();
+  if (grp != 0 || i >= npair * 256) return;
+  sum = 0;
+#pragma unroll
+  for (int g2 = 0; g2 < 16; ++g2) sum += part[g2][e];
   int p = i / 256, rem = i % 256, reg = rem / 64, lane = rem % 64;
   int ta = 0;
   while (p >= nt - ta) { p -= nt - ta; ++ta; }
@@ -89,57 +100,59 @@ __global__ void gram_reduce_kernel(const double* __restrict__ slabs, int nslabs,
 }
 
 // ---------------------------------------------------------------- Cholesky + inverse
-// One workgroup.  R upper with G = R^T R on the leading l x l block.  A pivot that falls below
-// 1e-13 of its original diagonal (rank-deficient panel) is replaced by that floor and counted
-// in *info; the direction it produces carries a ~zero singular value downstream.
-__global__ void __launch_bounds__(256)
+// One workgroup, one thread per column, everything in LDS.  Row-by-row (left-looking) upper
+// Cholesky: R[k][j] = (G[k][j] - sum_{t<k} R[t][k] R[t][j]) / R[k][k]; every thread walks the same
+// t-loop, so R[t][k] is an LDS broadcast and R[t][j] is conflict-free.  R^-1 by back substitution,
+// again one column per thread, with the inverse parked in the unused strict lower triangle
+// (Rinv[t][j], t < j, lives at a[j][t]) and its diagonal in dinv[].  A pivot that falls below
+// 1e-13 of the panel's scale (rank-deficient panel) is replaced by that floor and counted in
+// *info; the direction it produces carries a ~zero singular value downstream.
+__global__ void __launch_bounds__(128)
 chol_inv_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
                 int* __restrict__ info) {
-  extern __shared__ double a[];  // l x l working copy (row-major, stride l)
-  __shared__ double pivot;
+  extern __shared__ double a[];  // l x (l+1) working copy + l diagonal inverses
+  const int st = l + 1;
+  double* dinv = a + (size_t)l * st;
   __shared__ int bad;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  if (tid == 0) bad = 0;
-  for (int i = tid; i < l * l; i += nth) a[i] = G[(i / l) * ld + (i % l)];
+  const int j = threadIdx.x;
+  if (j == 0) bad = 0;
+  for (int i = threadIdx.x; i < l * l; i += blockDim.x) a[(i / l) * st + (i % l)] = G[(i / l) * ld + (i % l)];
   __syncthreads();
   double scale = 0;
-  for (int i = 0; i < l; ++i) scale = fmax(scale, fabs(G[i * ld + i]));
+  for (int i = 0; i < l; ++i) scale = fmax(scale, fabs(a[i * st + i]));
+  const double floor_ = scale * 1e-13 + 1e-300;
   for (int kk = 0; kk < l; ++kk) {
-    if (tid == 0) {
-      double d = a[kk * l + kk];
-      const double floor_ = fmax(fabs(G[kk * ld + kk]), scale * 1e-3) * 1e-13 + 1e-300;
-      if (!(d > floor_)) { d = floor_; bad += 1; }
-      pivot = sqrt(d);
-      a[kk * l + kk] = pivot;
+    double v = 0;
+    if (j >= kk && j < l) {
+      v = a[kk * st + j];
+      for (int t = 0; t < kk; ++t) v -= a[t * st + kk] * a[t * st + j];
+    }
+    if (j == kk) {
+      if (!(v > floor_)) { v = floor_; bad += 1; }
+      v = sqrt(v);
+      a[kk * st + kk] = v;
+      dinv[kk] = 1.0 / v;
     }
     __syncthreads();
-    const double inv = 1.0 / pivot;
-    for (int j = kk + 1 + tid; j < l; j += nth) a[kk * l + j] *= inv;
-    __syncthreads();
-    const int rem = l - kk - 1;
-    for (int t = tid; t < rem * rem; t += nth) {
-      const int i = kk + 1 + t / rem, j = kk + 1 + t % rem;
-      if (j >= i) a[i * l + j] -= a[kk * l + i] * a[kk * l + j];
-    }
+    if (j > kk && j < l) a[kk * st + j] = v * dinv[kk];
     __syncthreads();
   }
-  for (int i = tid; i < ld * ld; i += nth) {
-    const int r = i / ld, c2 = i % ld;
-    R[i] = (r < l && c2 < l && c2 >= r) ? a[r * l + c2] : 0.0;
-    Rinv[i] = 0.0;
-  }
-  __syncthreads();
-  // column j of R^-1 by back substitution; one thread per column, reading R from LDS
-  for (int j = tid; j < l; j += nth) {
-    Rinv[j * ld + j] = 1.0 / a[j * l + j];
+  // x = column j of R^-1: x_j = 1/R_jj, x_i = -(sum_{i<t<=j} R[i][t] x_t) / R_ii
+  if (j < l) {
     for (int i = j - 1; i >= 0; --i) {
-      double s = 0;
-      for (int t = i + 1; t <= j; ++t) s += a[i * l + t] * Rinv[t * ld + j];
-      Rinv[i * ld + j] = -s / a[i * l + i];
+      double s = a[i * st + j] * dinv[j];
+      for (int t = i + 1; t < j; ++t) s += a[i * st + t] * a[j * st + t];
+      a[j * st + i] = -s * dinv[i];
     }
   }
   __syncthreads();
-  if (tid == 0 && bad) atomicAdd(info, bad);
+  for (int i = threadIdx.x; i < ld * ld; i += blockDim.x) {
+    const int r = i / ld, c2 = i % ld;
+    const bool in = r < l && c2 < l;
+    R[i] = (in && c2 >= r) ? a[r * st + c2] : 0.0;
+    Rinv[i] = !in ? 0.0 : (c2 > r ? a[c2 * st + r] : (c2 == r ? dinv[r] : 0.0));
+  }
+  if (j == 0 && bad) atomicAdd(info, bad);
 }
 
 // ---------------------------------------------------------------- panel GEMM
@@ -216,12 +229,14 @@ __global__ void colsum_partial_kernel(const T* __restrict__ P, int64_t rows, int
 }
 
 template <typename T>
-__global__ void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int ld, T* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ld) return;
+__global__ void __launch_bounds__(64)
+colsum_final_kernel(const double* __restrict__ partial, int nblocks, int ld, T* __restrict__ out) {
+  const int j = blockIdx.x;
   double s = 0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * ld + j];
-  out[j] = (T)s;
+  for (int b = threadIdx.x; b < nblocks; b += WAVE) s += partial[(int64_t)b * ld + j];
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (threadIdx.x == 0) out[j] = (T)s;
 }
 
 template <typename T>
@@ -361,7 +376,7 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
   const int nt = ld / 16;
   const int npair = nt * (nt + 1) / 2;
   int nblocks = (int)((rows + 15) / 16);
-  if (nblocks > 512) nblocks = 512;
+  if (nblocks > 256) nblocks = 256;
   if (nblocks < 1) nblocks = 1;
   double* slabs = scratch.as<double>((size_t)nblocks * npair * 256);
   switch (nt) {
@@ -374,19 +389,19 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
     case 7: launch_gram<T, 7>(P, rows, ld, slabs, nblocks, s); break;
     default: launch_gram<T, 8>(P, rows, ld, slabs, nblocks, s); break;
   }
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 255) / 256), dim3(256), 0, s, slabs, nblocks, nt, ld, G);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, nt, ld, G);
   SAPCA_HIP(hipGetLastError());
 }
 
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
-  const size_t lds = (size_t)l * l * sizeof(double);
+  const size_t lds = ((size_t)l * (l + 1) + l) * sizeof(double);
   static size_t attr_bytes = 0;
   if (lds > 48 * 1024 && lds > attr_bytes) {
     SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_bytes = lds;
   }
-  hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds, s, G, l, ld, R, Rinv, info);
+  hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(128), lds, s, G, l, ld, R, Rinv, info);
   SAPCA_HIP(hipGetLastError());
 }
 
@@ -413,12 +428,12 @@ void weighted_colsum(const T* P, int64_t rows, int ld, const T* w, T* out, DevBu
   int by = 256 / ld;
   if (by < 1) by = 1;
   int nblocks = (int)((rows + by * 8 - 1) / (by * 8));
-  if (nblocks > 512) nblocks = 512;
+  if (nblocks > 256) nblocks = 256;
   if (nblocks < 1) nblocks = 1;
   double* partial = scratch.as<double>((size_t)nblocks * ld);
   hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(nblocks), dim3(ld, by), (size_t)by * ld * sizeof(double), s, P,
                      rows, ld, w, partial);
-  hipLaunchKernelGGL((colsum_final_kernel<T>), dim3((ld + 63) / 64), dim3(64), 0, s, partial, nblocks, ld, out);
+  hipLaunchKernelGGL((colsum_final_kernel<T>), dim3(ld), dim3(64), 0, s, partial, nblocks, ld, out);
   SAPCA_HIP(hipGetLastError());
 }
 

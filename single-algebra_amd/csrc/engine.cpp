@@ -45,6 +45,7 @@ void collect_timings(sapca_handle_s& h, bool is_fit) {
     t.transform_ms = 0;
   }
   for (auto& sp : h.spans) {
+    if (is_fit == (sp.first == C_TRANSFORM)) continue;  // fit spans on fit, transform spans on transform
     const double ms = h.timer.ms(sp.second);
     switch (sp.first) {
       case C_PREPARE: t.prepare_ms += ms; break;
