@@ -319,3 +319,66 @@ def test_properties_at_scale():
     pc = _builder(k, 8, 2).transform_semantics(L.TRANSFORM_CENTERED).build()
     tc = pc.fit_transform(x).double()
     np.testing.assert_allclose((tc ** 2).sum(0).cpu().numpy() / (m - 1), pc.explained_variance_(np.float64), rtol=2e-3)
+
+
+# ------------------------------------------------------------------ G6: Lanczos (uncentred: quirk Q1)
+@pytest.mark.parametrize("dtype,srel,ang", [(torch.float64, 1e-5, 1e-4), (torch.float32, 1e-4, 1e-4)])
+def test_g6_lanczos_uncentred(golden, dtype, srel, ang):
+    g = golden("g6_lanczos.npz")
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    dev = synth.gapped_csr(m, n, float(g["density"]), k, seed=int(g["seed"]), centred=False, dtype=dtype, device="cuda")
+    assert dev[2].numel() == int(g["nnz"])
+    x = sapca.DeviceCsr(*dev, (m, n))
+    pca = sapca.SparsePCABuilder.new().n_components(k).build()          # default method: Lanczos (pca/mod.rs:64-68)
+    pca.fit(x)
+    np.testing.assert_allclose(pca.singular_values_(np.float64), g["exact_s"][:k], rtol=srel)    # kappa = 1e-5
+    assert O.subspace_angle(pca.components_(np.float64), g["exact_vt"]) < ang
+    c = pca.components_(np.float64)
+    assert np.all(c[np.arange(k), np.argmax(np.abs(c), 1)] > 0)                                   # svd_flip
+    np.testing.assert_allclose(np.abs(c @ g["exact_vt"].T), np.eye(k), atol=2e-3)                 # vector by vector
+    # centring is computed (mean_, total variance) but the SVD ignores it
+    ptr, idx, val = csr_np(dev)
+    np.testing.assert_allclose(pca.mean_(np.float64), np.asarray(mat(ptr, idx, val, m, n).mean(0)).ravel(), rtol=1e-5, atol=1e-7)
+    ev = pca.explained_variance_(np.float64)
+    np.testing.assert_allclose(ev, g["exact_s"][:k] ** 2 / (m - 1), rtol=2 * srel)
+    assert pca.timings().lanczos_steps >= k
+    # transform still uses the mean (Q2 restatement evaluated with the fitted state)
+    t = pca.transform(x).cpu().numpy()
+    want = O.transform_sparse(ptr, idx, val.astype(np.float64), m, n, c, pca.mean_(np.float64), True)
+    np.testing.assert_allclose(t, want, atol=(1e-8 if dtype == torch.float64 else 2e-3) * np.abs(want).max())
+
+
+def test_g6_lanczos_masked(golden):
+    g = golden("g6_lanczos.npz")
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    dev = synth.gapped_csr(m, n, float(g["density"]), k, seed=int(g["seed"]), centred=False, dtype=torch.float64, device="cuda")
+    est = sapca.MaskedSparsePCABuilder.new().n_components(k).mask(g["mask"]).svd_method(SVDMethod.Lanczos()).build()
+    est.fit(sapca.DeviceCsr(*dev, (m, n)))
+    np.testing.assert_allclose(est.singular_values_(), g["masked_s"][:k], rtol=1e-5)
+    assert O.subspace_angle(est.components_(), g["masked_vt"]) < 1e-4
+    assert est.components_().shape == (k, int(g["mask"].sum())) and est.mean_().shape == (n,)
+
+
+def test_lanczos_wide_matrix_uses_the_small_side():
+    """m < n: las2 iterates on A A^T and recovers the right vectors."""
+    m, n, k = 300, 2000, 5
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.08, k, seed=13, centred=False, dtype=torch.float64))
+    A = mat(ptr, idx, val, m, n)
+    pca = sapca.SparsePCABuilder.new().n_components(k).build()
+    pca.fit(A)
+    _, s, vt = np.linalg.svd(A.toarray(), full_matrices=False)
+    np.testing.assert_allclose(pca.singular_values_(), s[:k], rtol=1e-5)
+    assert O.subspace_angle(pca.components_(), vt[:k]) < 1e-4
+
+
+def test_lanczos_vs_oracle_and_rank_error():
+    ptr, idx, val = csr_np(synth.flat_csr(400, 60, 0.2, seed=5, dtype=torch.float64))
+    A = mat(ptr, idx, val, 400, 60)
+    want = O.fit(ptr, idx, val, 400, 60, n_components=6, method="LANCZOS")
+    pca = sapca.SparsePCABuilder.new().n_components(6).build()
+    pca.fit(A)
+    np.testing.assert_allclose(pca.singular_values_(), want.singular_values, rtol=1e-5)
+    too_many = sapca.SparsePCABuilder.new().n_components(61).build()
+    with pytest.raises(L.SapcaError, match="SVD computation failed") as e:
+        too_many.fit(A)
+    assert e.value.status == L.ERR_SVD
