@@ -203,7 +203,10 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
     SAPCA_CHECK(l >= 1 && l <= 128 && In && Out, SAPCA_ERR_ARG, "spmm: panel width must be in [1, 128]");
     CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
     hipStream_t s = h->stream;
-    const int ld = (int)sapca::round_up((int64_t)l, 16);
+    // spmm_variant == 2 exercises the LDS-staged sweep on its own (f32 only): panels padded to 64/128
+    bool want_tiled = false;
+    if constexpr (sizeof(T) == 4) want_tiled = h->opt.spmm_variant == 2;
+    const int ld = want_tiled ? (l <= 64 ? 64 : 128) : (int)sapca::round_up((int64_t)l, 16);
     const uint64_t in_rows = transposed ? m : n, out_rows = transposed ? n : m;
     T* stage = h->scratch2.as<T>(std::max<uint64_t>(in_rows * l, out_rows * l) + n + 2 * 128);
     T* X = h->panel_x.as<T>(std::max<uint64_t>(in_rows, 1) * ld);
@@ -221,7 +224,13 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
     SAPCA_HIP(hipStreamSynchronize(s));
     if (!transposed) {
       if (mu) sapca::k::weighted_colsum(X, (int64_t)n, ld, d_mu, cvec, h->scratch, s);
-      sapca::k::spmm(A, nullptr, X, ld, Y, ld, ld, mu ? cvec : nullptr, h->opt.spmm_variant, s);
+      const sapca::TiledOp* top = nullptr;
+      if constexpr (sizeof(T) == 4) {
+        if (want_tiled) {
+          if (sapca::k::build_tiled(A, ld, h->tiled_a, h->tb_a, s)) top = &h->tiled_a;   // else: row kernel
+        }
+      }
+      sapca::k::spmm(A, top, X, ld, Y, ld, ld, mu ? cvec : nullptr, h->opt.spmm_variant, h->split_scratch, s);
     } else {
       int64_t* at_ptr = h->at_ptr.as<int64_t>(n + 1);
       int32_t* at_idx = h->at_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
@@ -229,7 +238,13 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
       sapca::k::transpose_csr(A, at_ptr, at_idx, at_val, h->scratch, s);
       CsrView<T> At;
       At.rows = (int64_t)n; At.cols = (int64_t)m; At.nnz = (int64_t)nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
-      sapca::k::spmm(At, nullptr, X, ld, Y, ld, ld, (const T*)nullptr, h->opt.spmm_variant, s);
+      const sapca::TiledOp* top = nullptr;
+      if constexpr (sizeof(T) == 4) {
+        if (want_tiled) {
+          if (sapca::k::build_tiled(At, ld, h->tiled_at, h->tb_at, s)) top = &h->tiled_at;
+        }
+      }
+      sapca::k::spmm(At, top, X, ld, Y, ld, ld, (const T*)nullptr, h->opt.spmm_variant, h->split_scratch, s);
       if (mu) {
         sapca::k::weighted_colsum(X, (int64_t)m, ld, (const T*)nullptr, svec, h->scratch, s);
         sapca::k::rank1_subtract(Y, (int64_t)n, ld, d_mu, svec, s);

@@ -72,11 +72,22 @@ struct CsrView {
   const T* val = nullptr;        // [nnz]
 };
 
-// Column-tiled companion of a CsrView for the LDS-staged sweep (see spmm.hip).
-struct TileIndex {
-  int tile_cols = 0;   // panel rows staged per LDS tile
-  int n_tiles = 0;
-  const int32_t* seg = nullptr;  // [rows][n_tiles+1] entry offsets relative to the row start
+// Tile-major companion of an f32 CSR operator for the LDS-staged sweep (spmm_tiled.hip).
+struct TiledOp {
+  bool valid = false;
+  int64_t rows = 0, cols = 0, total_entries = 0;
+  int ldp = 0;              // panel leading dimension (floats) the format was built for: 64 or 128
+  int tc = 0, nct = 0;      // panel rows per column tile, number of tiles
+  int nrb = 0;              // row blocks (one workgroup each)
+  int nsplit = 1, tiles_per_split = 0;
+  const int32_t* blk_row0 = nullptr;   // [nrb+1]
+  const int64_t* chunk_off = nullptr;  // [nrb*nct+1] entry offsets
+  const uint32_t* wave_off = nullptr;  // [nrb*nct][8]
+  const uint8_t* steps = nullptr;      // [nrb*nct][256]
+  const void* ent = nullptr;           // {u32 lds byte offset, f32 value}
+};
+struct TiledBuffers {
+  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc;
 };
 
 struct Stream {

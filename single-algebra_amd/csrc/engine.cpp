@@ -165,6 +165,27 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     h.at_used = {n, m, nnz, At.ptr, At.idx, At.val};
   }
 
+  // tile-major companions for the LDS-staged sweep (f32; panel width from the requested rank)
+  h.tiled_a = TiledOp();
+  h.tiled_at = TiledOp();
+  if constexpr (sizeof(T) == 4) {
+    if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && n_used > 0) {
+      Scope sc(h, C_PREPARE);
+      const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples),
+                                          std::min<int64_t>((int64_t)h.m_global, n_used));
+      if (l >= 1 && l <= 128) {
+        const int ldp = l <= 64 ? 64 : 128;
+        const bool ok_a = k::build_tiled(view(h.a_used), ldp, h.tiled_a, h.tb_a, s);
+        const bool ok_at = ok_a && k::build_tiled(view(h.at_used), ldp, h.tiled_at, h.tb_at, s);
+        if (h.opt.verbose)
+          fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
+                  ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
+                  ok_at ? "ok" : "no", h.tiled_at.nrb, h.tiled_at.nct, h.tiled_at.nsplit, (long long)h.tiled_at.total_entries);
+        if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }
+      }
+    }
+  }
+
   h.prep_key.ptr = A.ptr; h.prep_key.idx = A.idx; h.prep_key.val = A.val;
   h.prep_key.m = (uint64_t)m; h.prep_key.n = (uint64_t)n; h.prep_key.nnz = (uint64_t)nnz;
   h.prep_key.mask_version = h.mask_version; h.prep_key.dtype = kDtype; h.prep_key.valid = true;
@@ -207,7 +228,8 @@ void Engine<T>::fit_randomized(H& h) {
   const int64_t l_req = (int64_t)h.opt.n_components + (int64_t)h.opt.n_oversamples;
   const int l = (int)std::min<int64_t>(l_req, std::min<int64_t>((int64_t)h.m_global, n_used));
   SAPCA_CHECK(l <= 128, SAPCA_ERR_ARG, "n_components + n_oversamples above 128 is not supported");
-  const int ld = (int)round_up(l, 16);
+  const bool tiled = h.tiled_a.valid && h.tiled_at.valid;
+  const int ld = tiled ? h.tiled_a.ldp : (int)round_up(l, 16);
   const int q = (int)h.opt.n_power_iterations;
   const int norm = h.opt.normalizer;
   const bool center = h.opt.center != 0;
@@ -243,12 +265,12 @@ void Engine<T>::fit_randomized(H& h) {
   auto sweep_A = [&]() {  // Y = Ac X   (R8)
     if (center) k::weighted_colsum(X, n_used, ld, mu, cvec, h.scratch2, s);
     Scope sc(h, C_SPMM);
-    k::spmm(A, h.tiles_a.seg ? &h.tiles_a : nullptr, X, ld, Y, ld, ld, center ? cvec : nullptr, variant, s);
+    k::spmm(A, &h.tiled_a, X, ld, Y, ld, ld, center ? cvec : nullptr, variant, h.split_scratch, s);
   };
   auto sweep_At = [&]() {  // X = Ac^T Y   (R9); partial products are summed over ranks
     {
       Scope sc(h, C_SPMMT);
-      k::spmm(At, h.tiles_at.seg ? &h.tiles_at : nullptr, Y, ld, X, ld, ld, (const T*)nullptr, variant, s);
+      k::spmm(At, &h.tiled_at, Y, ld, X, ld, ld, (const T*)nullptr, variant, h.split_scratch, s);
     }
     if (h.comm.active()) h.comm.allreduce(X, (uint64_t)n_used * ld, kDtype, s);
     if (center) {
@@ -400,7 +422,8 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
                 h.spans.end());
   if (h.spans.empty()) h.timer.begin_collect(s, h.opt.collect_timings != 0);
   const int64_t m = A.rows, n = A.cols, n_used = (int64_t)h.n_used;
-  const int k = (int)h.k, ldk = (int)round_up(k, 16);
+  const int k = (int)h.k;
+  int ldk = (int)round_up(k, 16);
   const bool center = h.opt.center != 0;
   const bool ref_sem = h.opt.transform_semantics == SAPCA_TRANSFORM_REFERENCE;
   if (m == 0) return;
@@ -410,6 +433,9 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     key.ptr = A.ptr; key.idx = A.idx; key.val = A.val; key.m = (uint64_t)m; key.n = (uint64_t)n;
     key.nnz = (uint64_t)A.nnz; key.mask_version = h.mask_version; key.dtype = kDtype; key.valid = true;
     const bool prepared = h.prep_key == key;
+    // the fitted matrix's tile-major format serves the projection sweep too (one row block per workgroup)
+    const TiledOp* top = (prepared && h.tiled_a.valid && h.tiled_a.nsplit == 1 && k <= h.tiled_a.ldp) ? &h.tiled_a : nullptr;
+    if (top) ldk = top->ldp;
     CsrView<T> Au;
     double* d_cnt = nullptr;
     if (prepared) {
@@ -447,7 +473,7 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       // Q2 (sparse/mod.rs:268-282): t_ik = sum_j cnt_j (x_ij - [center] mu_j) V_kj
       k::scaled_transpose(comps, n_used, k, d_cnt, W, ldk, s);
       if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
-      k::spmm(Au, nullptr, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, s);
+      k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
     } else if (ref_sem && masked) {
       // Q3 (sparse_masked/mod.rs:488-529): mean subtracted at stored, kept entries only
       k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
@@ -457,12 +483,12 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
         k::subtract_column_mean(Au, mu, sv, s);
         As.val = sv;
       }
-      k::spmm(As, nullptr, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, s);
+      k::spmm(As, center ? nullptr : top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
     } else {
       // opt-in: the mathematically centred projection (A - 1 mu^T) V^T
       k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
       if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
-      k::spmm(Au, nullptr, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, s);
+      k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
     }
   }
   SAPCA_HIP(hipStreamSynchronize(s));

@@ -62,8 +62,9 @@ struct sapca_handle_s {
   sapca::DevBuf mean_used_dev, o2m_dev, sel_rows_dev;
   sapca::DevBuf components_dev;                                  // k x n_used, T
   sapca::DevBuf lanczos_buf;
-  sapca::DevBuf tile_a, tile_at;                                 // tile indices for the LDS sweep
-  sapca::TileIndex tiles_a, tiles_at;
+  sapca::TiledBuffers tb_a, tb_at;                               // tile-major formats for the LDS-staged sweep
+  sapca::TiledOp tiled_a, tiled_at;
+  sapca::DevBuf split_scratch;
 
   sapca::EventTimer timer;
   std::vector<std::pair<int, int>> spans;  // (category, event index) of the last fit/transform

@@ -40,8 +40,16 @@ void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* 
 // Y[r][j] = sum_e val_e X[col_e][j] - cvec[j]   for j < ncols; X has leading dimension ldx
 // (multiple of 16/sizeof(T)... see spmm.hip), Y leading dimension ldy.  cvec may be null.
 template <typename T>
-void spmm(const CsrView<T>& A, const TileIndex* tiles, const T* X, int ldx, T* Y, int ldy, int ncols,
-          const T* cvec, int variant, hipStream_t s);
+void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, int ldy, int ncols,
+          const T* cvec, int variant, DevBuf& scratch, hipStream_t s);
+
+// ---- spmm_tiled.hip ---------------------------------------------------------------------
+// Builds the tile-major format of an f32 operator for panels of leading dimension ldp (64/128).
+// Returns false (op.valid == false) when the operator does not fit the LDS staging; callers then
+// stay on the row kernel.
+bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
+void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
+                hipStream_t s);
 
 // ---- dense.hip -------------------------------------------------------------------------
 // G = P^T P (ld x ld, f64, full symmetric) for a rows x ld panel with ld % 16 == 0, ld <= 128.

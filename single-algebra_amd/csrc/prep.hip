@@ -76,6 +76,30 @@ __global__ void gather_transposed_kernel(const uint32_t* __restrict__ perm, cons
   }
 }
 
+// packed[e] = (row << 32) | bits(val[e]): the payload the radix sort carries for f32 matrices
+__global__ void pack_rows_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ val, int64_t rows,
+                                 uint64_t* __restrict__ packed) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE)
+      packed[e] = ((uint64_t)(uint32_t)r << 32) | (uint64_t)__float_as_uint(val[e]);
+  }
+}
+
+__global__ void unpack_rows_kernel(const uint64_t* __restrict__ packed, int64_t count, int32_t* __restrict__ t_idx,
+                                   float* __restrict__ t_val) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    const uint64_t p = packed[i];
+    t_idx[i] = (int32_t)(p >> 32);
+    t_val[i] = __uint_as_float((uint32_t)p);
+  }
+}
+
 template <typename T>
 __global__ void row_sums_kernel(const int64_t* __restrict__ ptr, const T* __restrict__ val, int64_t rows,
                                 double* __restrict__ sum, double* __restrict__ sumsq) {
@@ -261,6 +285,28 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
   }
   int bits = 1;
   while ((1ll << bits) < A.cols) ++bits;
+  if constexpr (sizeof(T) == 4) {
+    // f32: the sort carries (row, value) itself -- no random gather pass afterwards
+    size_t sort_bytes = 0;
+    SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
+    const size_t a4 = (size_t)round_up(nnz * 4, 256), a8 = (size_t)round_up(nnz * 8, 256);
+    char* base = static_cast<char*>(scratch.ensure(a4 + 2 * a8 + sort_bytes + 256));
+    uint32_t* keys_out = reinterpret_cast<uint32_t*>(base);
+    uint64_t* packed = reinterpret_cast<uint64_t*>(base + a4);
+    uint64_t* packed_out = reinterpret_cast<uint64_t*>(base + a4 + a8);
+    void* tmp = base + a4 + 2 * a8;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr,
+                       reinterpret_cast<const float*>(A.val), A.rows, packed);
+    SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, reinterpret_cast<const uint32_t*>(A.idx), keys_out, packed,
+                                        packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+    hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out, nnz,
+                       A.cols, t_ptr);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, packed_out, nnz, t_idx,
+                       reinterpret_cast<float*>(t_val));
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
   size_t sort_bytes = 0;
   rocprim::counting_iterator<uint32_t> iota(0);
   SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, iota,

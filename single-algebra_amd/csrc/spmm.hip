@@ -132,15 +132,22 @@ void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, i
 }  // namespace
 
 template <typename T>
-void spmm(const CsrView<T>& A, const TileIndex* tiles, const T* X, int ldx, T* Y, int ldy, int ncols, const T* cvec,
-          int variant, hipStream_t s) {
+void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, int ldy, int ncols, const T* cvec,
+          int variant, DevBuf& scratch, hipStream_t s) {
   constexpr int VEC = Vec<T>::N;
   SAPCA_CHECK(ldx % VEC == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, SAPCA_ERR_ARG,
               "spmm: panel must be 16-byte aligned with a leading dimension that is a multiple of 16 bytes");
   SAPCA_CHECK(ncols <= ldx && ncols <= ldy, SAPCA_ERR_ARG, "spmm: ncols exceeds a leading dimension");
   if (A.rows == 0) return;
-  (void)tiles;
-  (void)variant;
+  if constexpr (sizeof(T) == 4) {
+    // variant 1 forces the row kernel; otherwise the LDS-staged sweep runs whenever its format exists
+    if (variant != 1 && tiled && tiled->valid && tiled->ldp == ldx && tiled->rows == A.rows && tiled->cols == A.cols &&
+        (tiled->nsplit == 1 || ldy == ldx)) {
+      spmm_tiled(*tiled, reinterpret_cast<const float*>(X), reinterpret_cast<float*>(Y), ldy, ncols,
+                 reinterpret_cast<const float*>(cvec), scratch, s);
+      return;
+    }
+  }
   const int lanes_needed = (ldx + VEC - 1) / VEC;
   if (lanes_needed <= 4) launch_rowgather<T, 4>(A, X, ldx, Y, ldy, ncols, cvec, s);
   else if (lanes_needed <= 8) launch_rowgather<T, 8>(A, X, ldx, Y, ldy, ncols, cvec, s);
@@ -149,8 +156,8 @@ void spmm(const CsrView<T>& A, const TileIndex* tiles, const T* X, int ldx, T* Y
   SAPCA_HIP(hipGetLastError());
 }
 
-template void spmm<float>(const CsrView<float>&, const TileIndex*, const float*, int, float*, int, int, const float*, int, hipStream_t);
-template void spmm<double>(const CsrView<double>&, const TileIndex*, const double*, int, double*, int, int, const double*, int, hipStream_t);
+template void spmm<float>(const CsrView<float>&, const TiledOp*, const float*, int, float*, int, int, const float*, int, DevBuf&, hipStream_t);
+template void spmm<double>(const CsrView<double>&, const TiledOp*, const double*, int, double*, int, int, const double*, int, DevBuf&, hipStream_t);
 
 }  // namespace k
 }  // namespace sapca

@@ -382,3 +382,56 @@ def test_lanczos_vs_oracle_and_rank_error():
     with pytest.raises(L.SapcaError, match="SVD computation failed") as e:
         too_many.fit(A)
     assert e.value.status == L.ERR_SVD
+
+
+# ------------------------------------------------------------------ the LDS-staged sweep on its own (variant 2)
+@pytest.fixture(scope="module")
+def session_tiled():
+    return ops.Session(spmm_variant=2)
+
+
+@pytest.mark.parametrize("l", [8, 30, 64])
+def test_g3_spmm_tiled(golden, session_tiled, l):
+    g = golden("g3_spmm.npz")
+    ptr, idx, val = g["indptr"], g["indices"], g["data"].astype(np.float32)
+    m, n, mu = int(g["m"]), int(g["n"]), g["mu"].astype(np.float32)
+    X, Yin = g[f"X{l}"].astype(np.float32), g[f"Yin{l}"].astype(np.float32)
+    s = session_tiled
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, X), g[f"AX{l}"], atol=2e-3)
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, X, mu), g[f"AcX{l}"], atol=2e-3)
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, Yin, None, transposed=True), g[f"AtY{l}"], atol=2e-3)
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, Yin, mu, transposed=True), g[f"ActY{l}"], atol=2e-3)
+
+
+@pytest.mark.parametrize("shape,dens,l", [((5000, 3000), 0.02, 60), ((700, 300), 0.05, 110), ((3000, 40000), 0.004, 60),
+                                          ((70000, 900), 0.01, 20), ((1000, 1000), 0.0, 16)])
+def test_spmm_tiled_matches_row_kernel(session, session_tiled, shape, dens, l):
+    """ragged shapes: several row blocks, split tile ranges, wide panels, an empty matrix; the two sweep
+    kernels must agree to f32 rounding on both A and A^T"""
+    m, n = shape
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, dens, seed=8, dtype=torch.float32))
+    X = synth.gaussian_panel(n, l, 3).numpy().astype(np.float32)
+    Yin = synth.gaussian_panel(m, l, 4).numpy().astype(np.float32)
+    a1, a2 = session.spmm(ptr, idx, val, m, n, X), session_tiled.spmm(ptr, idx, val, m, n, X)
+    scale = max(1.0, float(np.abs(a1).max()))
+    np.testing.assert_allclose(a2, a1, atol=2e-5 * scale)
+    b1 = session.spmm(ptr, idx, val, m, n, Yin, None, transposed=True)
+    b2 = session_tiled.spmm(ptr, idx, val, m, n, Yin, None, transposed=True)
+    np.testing.assert_allclose(b2, b1, atol=2e-5 * max(1.0, float(np.abs(b1).max())))
+    if dens > 0:
+        want = mat(ptr, idx, val, m, n).astype(np.float64) @ X.astype(np.float64)
+        np.testing.assert_allclose(a2, want, atol=1e-4 * scale)
+
+
+def test_fit_is_the_same_with_either_sweep_kernel(golden):
+    g = golden("g4_randomized_fit.npz")
+    m, n, k, p, q = (int(g[x]) for x in "mnkpq")
+    A = mat(g["indptr"], g["indices"], g["data"].astype(np.float32), m, n)
+    res = []
+    for variant in (1, 2):
+        pca = _builder(k, p, q).spmm_variant(variant).build().set_omega(g["omega"])
+        t = pca.fit_transform(A)
+        res.append((pca.singular_values_(np.float64), pca.components_(np.float64), t))
+        np.testing.assert_allclose(res[-1][0], g["s"], rtol=1e-4)
+        assert O.subspace_angle(res[-1][1], g["vt"]) < 1e-4
+    np.testing.assert_allclose(res[0][2], res[1][2], atol=2e-3 * np.abs(res[0][2]).max())
