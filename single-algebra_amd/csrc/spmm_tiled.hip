@@ -38,15 +38,15 @@ namespace k {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int WAVES = 16;         // waves per workgroup
 constexpr int RW = 32;            // max rows per wave (register accumulators)
-constexpr int BLOCK_ROWS = WAVES * RW;
-constexpr int THREADS = WAVES * WAVE;
+constexpr int BLOCK_ROWS = 512;   // stride of the per-(block, tile) step table; max rows per block
+// lane groups ("slots") per wave: 2 half-waves (16 waves/workgroup, 512 rows) or 4 quarter-waves
+// (8 waves/workgroup, 256 rows, half the LDS instructions per entry)
+constexpr int waves_for(int slots) { return slots == 2 ? 16 : 8; }
 constexpr int TILE_BYTES = 96 * 1024;
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int STAGE_BYTES = LDS_TOTAL - TILE_BYTES - 1024;   // entry staging capacity
 constexpr int STAGE_ENTRIES = STAGE_BYTES / 8 - WAVE;        // keep one chunk of slack for read-ahead
-constexpr int PAD = 2;            // entries per wave-step (one per half-wave)
 
 struct Ent { uint32_t off; float val; };
 
@@ -54,6 +54,7 @@ struct Ent { uint32_t off; float val; };
 // seg[r][t] (t = 0..nct) = number of entries of row r with col < t*TC  (prep.hip: tile_index_kernel)
 
 // one block per (row block, column tile): batch counts, wave offsets, chunk size
+template <int WAVES, int PAD>
 __global__ void __launch_bounds__(BLOCK_ROWS)
 tiled_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct,
                    uint8_t* __restrict__ steps, uint32_t* __restrict__ wave_off, int64_t* __restrict__ chunk_size) {
@@ -85,7 +86,8 @@ tiled_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ 
 }
 
 // one block per row block; wave w copies its rows' entries into every column tile's chunk
-__global__ void __launch_bounds__(THREADS)
+template <int WAVES, int PAD>
+__global__ void __launch_bounds__(WAVES * WAVE)
 tiled_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                   const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, int tc,
                   int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ wave_off,
@@ -143,7 +145,7 @@ template <> struct Lane<4> {
 
 // U consecutive steps of one row: entry reads first, panel gathers next, FMAs last, so U gathers
 // per wave are in flight.
-template <int VPL, int U>
+template <int VPL, int PAD, int U>
 __device__ __forceinline__ void steps_batch(typename Lane<VPL>::V& acc, const char* stage_lane, const char* tile_lane) {
   typedef unsigned int u2 __attribute__((ext_vector_type(2)));
   u2 e[U];
@@ -157,17 +159,17 @@ __device__ __forceinline__ void steps_batch(typename Lane<VPL>::V& acc, const ch
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int NP_TILE = TILE_BYTES / (THREADS * 16);                     // 6 float4 per thread
-constexpr int NP_STAGE = (STAGE_BYTES + THREADS * 16 - 1) / (THREADS * 16);  // 4
+constexpr int np_tile(int threads) { return TILE_BYTES / (threads * 16); }
+constexpr int np_stage(int threads) { return (STAGE_BYTES + threads * 16 - 1) / (threads * 16); }
 
 // loads are unconditional (addresses clamped into the valid range) so the arrays stay in VGPRs
-template <int N>
+template <int N, int THREADS>
 __device__ __forceinline__ void load_regs(v4f (&r)[N], const char* src, int bytes) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
     r[i] = *reinterpret_cast<const v4f*>(src + min((i * THREADS + (int)threadIdx.x) * 16, bytes - 16));
 }
-template <int N>
+template <int N, int THREADS>
 __device__ __forceinline__ void store_regs(const v4f (&r)[N], char* dst, int capacity) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -181,21 +183,24 @@ __device__ __forceinline__ void store_regs(const v4f (&r)[N], char* dst, int cap
     const int64_t cidx_ = (int64_t)rb * nct + (CT);                                                 \
     const int64_t c_lo_ = chunk_off[cidx_];                                                         \
     const int64_t first_ = (int64_t)(CT) * tc;                                                      \
-    load_regs<NP_TILE>(pt, reinterpret_cast<const char*>(X + first_ * LDP),                         \
+    load_regs<NP_TILE, THREADS>(pt, reinterpret_cast<const char*>(X + first_ * LDP),                         \
                        (int)min<int64_t>(tc, panel_rows - first_) * LDP * 4);                       \
-    load_regs<NP_STAGE>(ps, reinterpret_cast<const char*>(ent + c_lo_),                             \
+    load_regs<NP_STAGE, THREADS>(ps, reinterpret_cast<const char*>(ent + c_lo_),                             \
                         max(16, (int)(chunk_off[cidx_ + 1] - c_lo_) * 8));                          \
   }
 
-template <int LDP, bool PREFETCH>  // LDP: panel leading dimension in floats (64 or 128)
-__global__ void __launch_bounds__(THREADS)
+template <int LDP, int SLOTS, bool PREFETCH>  // LDP: panel leading dimension in floats (64 or 128)
+__global__ void __launch_bounds__(waves_for(SLOTS) * WAVE)
 spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const int64_t* __restrict__ chunk_off,
                   const uint32_t* __restrict__ wave_off, const uint8_t* __restrict__ steps,
                   const Ent* __restrict__ ent, int64_t panel_rows, const float* __restrict__ X, int nsplit,
                   int tiles_per_split, float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols,
                   const float* __restrict__ cvec, int mode) {
-  constexpr int VPL = LDP / 32;   // panel values per lane: the half-wave's 32 lanes cover one panel row
-  constexpr int RWK = LDP == 64 ? RW : RW / 2;   // rows per wave: the accumulators must fit 128 VGPRs
+  constexpr int WAVES = waves_for(SLOTS), THREADS = WAVES * WAVE, PAD = SLOTS;
+  constexpr int LPE = WAVE / SLOTS;   // lanes that cover one panel row
+  constexpr int VPL = LDP / LPE;      // panel values per lane
+  constexpr int RWK = (SLOTS == 2 && LDP == 128) ? RW / 2 : RW;   // rows per wave: the accumulators must fit the VGPR budget
+  constexpr int NP_TILE = np_tile(THREADS), NP_STAGE = np_stage(THREADS);
   using LN = Lane<VPL>;
   using V = typename LN::V;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -204,7 +209,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
   const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  const int half = lane >> 5, q = lane & 31;
+  const int half = lane / LPE, q = lane % LPE;   // half = lane group (slot)
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int rpw = (nrows + WAVES - 1) / WAVES;
   const int my_rows = max(0, min(nrows - wave * rpw, rpw));
@@ -220,8 +225,8 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
     const int64_t cidx = (int64_t)rb * nct + ct;
     __syncthreads();  // the previous tile's readers are done
     if (!PREFETCH && (!(mode & 2) || ct == ct0)) SAPCA_PREFETCH(ct)
-    store_regs<NP_TILE>(pt, tile, TILE_BYTES);
-    store_regs<NP_STAGE>(ps, stage, STAGE_BYTES);
+    store_regs<NP_TILE, THREADS>(pt, tile, TILE_BYTES);
+    store_regs<NP_STAGE, THREADS>(ps, stage, STAGE_BYTES);
     __syncthreads();
     if (PREFETCH && ct + 1 < ct1) SAPCA_PREFETCH(ct + 1)
     if (mode & 1) continue;
@@ -233,17 +238,17 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
       for (int rr = 0; rr < RWK; ++rr) {
         int n = __builtin_amdgcn_readlane(cnt_v, rr);
         while (n >= 4) {
-          steps_batch<VPL, 4>(acc[rr], sl, tl);
+          steps_batch<VPL, PAD, 4>(acc[rr], sl, tl);
           sl += 4 * PAD * 8;
           n -= 4;
         }
         if (n >= 2) {
-          steps_batch<VPL, 2>(acc[rr], sl, tl);
+          steps_batch<VPL, PAD, 2>(acc[rr], sl, tl);
           sl += 2 * PAD * 8;
           n -= 2;
         }
         if (n) {
-          steps_batch<VPL, 1>(acc[rr], sl, tl);
+          steps_batch<VPL, PAD, 1>(acc[rr], sl, tl);
           sl += PAD * 8;
         }
       }
@@ -260,7 +265,9 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
   for (int rr = 0; rr < RWK; ++rr) {
     V a = acc[rr];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) a[i] += __shfl_xor(a[i], 32);
+    for (int off = LPE; off < WAVE; off <<= 1)
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) a[i] += __shfl_xor(a[i], off);
     if (rr < my_rows && half == 0) {
       float* y = dst_base + (int64_t)(row0 + wave * rpw + rr) * ldo + col;
 #pragma unroll
@@ -287,16 +294,16 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 
 #undef SAPCA_PREFETCH
 
-template <int LDP, bool PREFETCH>
+template <int LDP, int SLOTS, bool PREFETCH>
 void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
                   hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tiled_kernel<LDP, PREFETCH>),
+    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tiled_kernel<LDP, SLOTS, PREFETCH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     attr = true;
   }
-  hipLaunchKernelGGL((spmm_tiled_kernel<LDP, PREFETCH>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(THREADS), LDS_TOTAL,
+  hipLaunchKernelGGL((spmm_tiled_kernel<LDP, SLOTS, PREFETCH>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(waves_for(SLOTS) * WAVE), LDS_TOTAL,
                      s, op.blk_row0, op.nct, op.tc, op.chunk_off, op.wave_off, op.steps,
                      reinterpret_cast<const Ent*>(op.ent), op.cols, X, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
                      ncols, cvec, mode);
@@ -313,7 +320,10 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   const int nct = (int)((A.cols + tc - 1) / tc);
   // row blocks of <= 512 rows.  With enough rows the block count is a multiple of the 256 CUs (every
   // CU runs the same number of workgroups); with few rows (A^T) the tile range is split instead.
-  const int block_rows = ldp == 64 ? BLOCK_ROWS : BLOCK_ROWS / 2;   // 16 waves x 32 (or 16) rows
+  static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
+  const int slots = (ldp == 64 && slots_env == 4) ? 4 : 2;
+  const int waves = waves_for(slots);
+  const int block_rows = waves * ((slots == 2 && ldp == 128) ? RW / 2 : RW);
   int64_t nrb = (A.rows + block_rows - 1) / block_rows;
   int nsplit = 1;
   if (nrb >= 192) {
@@ -340,11 +350,15 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     nchunks = nrb * nct;
     d_blk = buf.blk.as<int32_t>((size_t)nrb + 1);
     d_steps = buf.steps.as<uint8_t>((size_t)nchunks * BLOCK_ROWS);
-    d_wave_off = buf.wave_off.as<uint32_t>((size_t)nchunks * WAVES);
+    d_wave_off = buf.wave_off.as<uint32_t>((size_t)nchunks * waves);
     d_chunk = buf.chunk_off.as<int64_t>((size_t)nchunks + 1);
     SAPCA_HIP(hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(tiled_count_kernel, dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct, d_steps,
-                       d_wave_off, d_chunk);
+    if (slots == 2)
+      hipLaunchKernelGGL((tiled_count_kernel<16, 2>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
+                         d_steps, d_wave_off, d_chunk);
+    else
+      hipLaunchKernelGGL((tiled_count_kernel<8, 4>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
+                         d_steps, d_wave_off, d_chunk);
     SAPCA_HIP(hipMemsetAsync(d_chunk + nchunks, 0, sizeof(int64_t), s));
     // maximum chunk size (staging capacity check), then exclusive scan of the sizes
     size_t tmp_bytes = 0, tmp2 = 0;
@@ -373,13 +387,17 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   }
   Ent* d_ent = reinterpret_cast<Ent*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(Ent)));
   SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
-  const size_t lds = (size_t)WAVES * nct * sizeof(uint32_t);
+  const size_t lds = (size_t)waves * nct * sizeof(uint32_t);
   SAPCA_CHECK(lds <= 64 * 1024, SAPCA_ERR_ARG, "tiled sweep: too many column tiles");
-  hipLaunchKernelGGL(tiled_fill_kernel, dim3((unsigned)nrb), dim3(THREADS), lds, s, A.ptr, A.idx, A.val, d_seg, d_blk,
-                     nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent);
+  if (slots == 2)
+    hipLaunchKernelGGL((tiled_fill_kernel<16, 2>), dim3((unsigned)nrb), dim3(16 * WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+                       d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent);
+  else
+    hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)nrb), dim3(8 * WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+                       d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent);
   SAPCA_HIP(hipGetLastError());
   op.rows = A.rows; op.cols = A.cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
-  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total;
+  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots;
   op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
@@ -400,11 +418,14 @@ void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols,
     nc = op.ldp;
   }
   const bool pf = !(mode & 4);
-  if (op.ldp == 64) {
-    if (pf) launch_tiled<64, true>(op, X, out, ldo, nc, cvec, mode, s);
-    else launch_tiled<64, false>(op, X, out, ldo, nc, cvec, mode, s);
+  if (op.ldp == 64 && op.slots == 4) {
+    if (pf) launch_tiled<64, 4, true>(op, X, out, ldo, nc, cvec, mode, s);
+    else launch_tiled<64, 4, false>(op, X, out, ldo, nc, cvec, mode, s);
+  } else if (op.ldp == 64) {
+    if (pf) launch_tiled<64, 2, true>(op, X, out, ldo, nc, cvec, mode, s);
+    else launch_tiled<64, 2, false>(op, X, out, ldo, nc, cvec, mode, s);
   } else {
-    launch_tiled<128, false>(op, X, out, ldo, nc, cvec, mode, s);
+    launch_tiled<128, 2, false>(op, X, out, ldo, nc, cvec, mode, s);
   }
   if (op.nsplit > 1) {
     const int64_t total = op.rows * (int64_t)op.ldp;
