@@ -34,6 +34,8 @@ WORKLOADS = {
     "c4": (1_000_000, 30_000, 0.03, 50, 10, 4),
     "c5": (2_000_000, 50_000, 0.01, 100, 10, 4),
     "small": (20_000, 4_000, 0.03, 20, 10, 4),
+    # BASELINE.json configs[2]: MaskedSparsePCA, f64, 60 % feature mask, SVDMethod::Lanczos k=30 (p, q unused)
+    "c3": (200_000, 30_000, 0.03, 30, 0, 0),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -69,6 +71,48 @@ def cpu_baseline(name, n, density, k, p, q, seed, gen_device="cpu"):
                       f"{dt:.2f} s; restatement of the reference algorithm, not the reference binary"}
 
 
+def bench_lanczos(args, rank, local_rank, world, dev):
+    """configs[2]: MaskedSparsePCA fit_transform, f64, Lanczos on the mask-compacted (uncentred) operator."""
+    import sapca
+    from sapca import synth
+    assert world == 1, "the c3 workload is a 1-GPU configuration"
+    m, n, density, k, _, _ = WORKLOADS["c3"]
+    ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=42, centred=False, dtype=torch.float64, device=dev)
+    mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
+    x = sapca.DeviceCsr(ptr, idx, val, (m, n))
+    est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).device(local_rank).collect_timings(True)
+           .svd_method(sapca.SVDMethod.Lanczos()).build())
+    for _ in range(args.warmup):
+        out = est.fit_transform(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lz_ms, steps = 0.0, 0
+    for _ in range(args.steps):
+        out = est.fit_transform(x)
+        t = est.timings()
+        lz_ms += t.lanczos_ms
+        steps += int(t.lanczos_steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_used = int(mask.sum())
+    nnz_used = int(mask[idx.cpu().numpy()].sum())
+    # SURVEY.md 8d: per Lanczos step 2*[nnz'*(8+4) + (m+1)*8] + (m + 2n')*8 bytes
+    step_bytes = 2 * (nnz_used * 12 + (m + 1) * 8) + (m + 2 * n_used) * 8
+    achieved = step_bytes * steps / (lz_ms * 1e-3) / 1e9
+    total_bytes = step_bytes * steps / args.steps + 2 * (val.numel() * 12 + (m + 1) * 8)   # + stats and transform passes
+    print(json.dumps({
+        "metric": "masked_sparse_pca_lanczos_fit_transform_algorithmic_throughput", "value": total_bytes / (dt / args.steps) / 1e9,
+        "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"c3: MaskedSparsePCA {m} x {n} CSR f64 density {density}, 60 % Bernoulli mask seed 7 ({n_used} kept), "
+                               f"SVDMethod::Lanczos k={k} (uncentred operator), inputs resident in HBM",
+                   "nnz": int(val.numel()), "nnz_masked": nnz_used, "lanczos_steps_per_fit": steps / args.steps},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "Lanczos step (SpMV pair + re-orthogonalisation), HIP events on the library stream",
+                     "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": lz_ms / max(steps, 1)}}))
+    assert out.shape == (m, k)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,23 +138,18 @@ def main():
     from sapca import synth
     m, n, density, k, p, q = WORKLOADS[args.workload]
     seed = 42
+    if args.workload == "c3":
+        return bench_lanczos(args, rank, local_rank, world, dev)
     ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=seed, row_start=rank * m, dtype=torch.float32, device=dev)
     x = sapca.DeviceCsr(ptr, idx, val, (m, n))
     nnz = x.nnz
     pca = (sapca.SparsePCABuilder.new().n_components(k).random_seed(42).device(local_rank).collect_timings(True)
            .spmm_variant(args.spmm_variant)
            .svd_method(sapca.SVDMethod.Random(p, q, sapca.PowerIterationNormalizer.QR)).build())
+    transport = "none"
     if world > 1:
-        from sapca import _lib as L
-        import ctypes as C
-        uid = [None]
-        if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            st = L.load().sapca_comm_unique_id(buf)
-            assert st == 0, "sapca_comm_unique_id failed"
-            uid[0] = bytes(buf)
-        dist.broadcast_object_list(uid, src=0)
-        pca.comm_init_rank(world, rank, uid[0])
+        from sapca import dist as sdist
+        transport = sdist.init_comm(pca)        # RCCL inside the library; torch.distributed callback as the fallback
 
     def barrier():
         if world > 1:
@@ -162,7 +201,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {m * world} x {n} CSR f32, density {density}, gapped generator seed {seed}, "
                                    f"SparsePCA fit_transform, SVDMethod::Random k={k} p={p} q={q} QR, rows range-partitioned "
-                                   f"over {world} GPU(s), inputs resident in HBM",
+                                   f"over {world} GPU(s), inputs resident in HBM, collectives: {transport}",
                        "nnz": int(nnz_total), "rows_per_gpu": m, "sweeps_per_fit": 2 * q + 2, "stage_ms": stage},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

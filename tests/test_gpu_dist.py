@@ -1,0 +1,65 @@
+"""Row-sharded fit on the GPU with two ranks (-m gpu).  The test box has ONE GPU, so both ranks use it and
+the all-reduce goes through the callback transport (gloo on host copies); the device kernels, the shard
+logic and the three all-reduce sites are the product's.  RCCL itself is exercised by bench.py --gpus N."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir, method):
+    import torch.distributed as dist
+    import sapca
+    from sapca import dist as sdist
+    from sapca import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        m, n, k, p, q = 6000, 900, 8, 8, 3
+        centred = method == "random"
+        full = synth.gapped_csr(m, n, 0.05, k, seed=23, centred=centred, dtype=torch.float32, device="cuda")
+        ptr = full[0].cpu().numpy()
+        r0, r1 = sdist.shard_rows(ptr, world)[rank]
+        lo, hi = int(ptr[r0]), int(ptr[r1])
+        shard = sapca.DeviceCsr((full[0][r0:r1 + 1] - lo).contiguous(), full[1][lo:hi].contiguous(),
+                                full[2][lo:hi].contiguous(), (r1 - r0, n))
+        sm = sapca.SVDMethod.Random(p, q) if method == "random" else sapca.SVDMethod.Lanczos()
+        om = synth.gaussian_panel(n, k + p, 5).numpy()
+        est = sapca.SparsePCABuilder.new().n_components(k).svd_method(sm).build().set_omega(om)
+        assert sdist.init_comm(est, prefer="torch", stage_through_host=True) == "torch"
+        t = est.fit_transform(shard)
+        # single-rank reference on the full matrix, same Omega
+        ref = sapca.SparsePCABuilder.new().n_components(k).svd_method(sm).build().set_omega(om)
+        t_ref = ref.fit_transform(sapca.DeviceCsr(*full, (m, n)))
+        np.testing.assert_allclose(est.singular_values_(np.float64), ref.singular_values_(np.float64), rtol=2e-5)
+        np.testing.assert_allclose(est.mean_(np.float64), ref.mean_(np.float64), atol=1e-6)
+        np.testing.assert_allclose(est.total_variance_(), ref.total_variance_(), rtol=1e-5)
+        import sapca_oracle as O
+        assert O.subspace_angle(est.components_(np.float64), ref.components_(np.float64)) < 1e-4
+        scale = float(t_ref.abs().max())
+        np.testing.assert_allclose(t.cpu().numpy(), t_ref[r0:r1].cpu().numpy(), atol=2e-3 * scale)
+        with open(os.path.join(tmpdir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["random", "lanczos"])
+def test_two_rank_row_sharded_fit(tmp_path, method):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), method), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
