@@ -39,8 +39,10 @@ void collect_timings(sapca_handle_s& h, bool is_fit) {
   sapca_timings& t = h.timings;
   if (is_fit) {
     const double keep_upload = t.upload_ms;
+    const uint64_t keep_steps = t.lanczos_steps;
     std::memset(&t, 0, sizeof(t));
     t.upload_ms = keep_upload;
+    t.lanczos_steps = keep_steps;
   } else {
     t.transform_ms = 0;
   }
@@ -345,6 +347,7 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
   h.timer.begin_collect(s, h.opt.collect_timings != 0);
   const int total_ev = h.timer.start();
   h.fitted = false;
+  h.timings.lanczos_steps = 0;
   SAPCA_CHECK(h.opt.n_components > 0, SAPCA_ERR_ARG, "n_components must be positive");
   SAPCA_CHECK(A.rows > 0 && A.cols > 0, SAPCA_ERR_ARG, "empty matrix");
   prepare(h, A);

@@ -1,0 +1,142 @@
+// sapca.hpp -- C++ mirror of single-algebra's sparse-PCA API over the C ABI (include/sapca.h).
+// Same names and argument meaning as the reference (src/dimred/pca: SVDMethod, SparsePCABuilder,
+// MaskedSparsePCABuilder, fit / transform / fit_transform / feature_importances /
+// explained_variance_ratio / cumulative_explained_variance_ratio); errors surface as sapca::Error
+// carrying the reference's messages.  Header-only; link with -lsapca.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/sapca.h"
+
+namespace sapca {
+
+struct Error : std::runtime_error {
+  sapca_status status;
+  Error(sapca_status s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+enum class PowerIterationNormalizer { QR = SAPCA_NORM_QR, LU = SAPCA_NORM_LU, None = SAPCA_NORM_NONE };
+
+// enum SVDMethod { Lanczos, Random { n_oversamples, n_power_iterations, normalizer } }   (pca/mod.rs:49-68)
+struct SVDMethod {
+  bool random = false;
+  size_t n_oversamples = 10, n_power_iterations = 4;
+  PowerIterationNormalizer normalizer = PowerIterationNormalizer::QR;
+  static SVDMethod Lanczos() { return {}; }
+  static SVDMethod Random(size_t p, size_t q, PowerIterationNormalizer n = PowerIterationNormalizer::QR) { return {true, p, q, n}; }
+};
+
+// nalgebra_sparse::CsrMatrix<T> as three borrowed arrays (usize == uint64_t indices)
+template <typename T>
+struct CsrRef {
+  uint64_t nrows, ncols, nnz;
+  const uint64_t* row_offsets;
+  const uint64_t* col_indices;
+  const T* values;
+};
+
+template <typename T> struct Abi;
+#define SAPCA_ABI(SUF, T)                                                                                        \
+  template <> struct Abi<T> {                                                                                    \
+    static sapca_status fit(sapca_handle h, const CsrRef<T>& x) { return sapca_fit_csr_##SUF(h, x.nrows, x.ncols, x.nnz, x.row_offsets, x.col_indices, x.values); } \
+    static sapca_status transform(sapca_handle h, const CsrRef<T>& x, T* o) { return sapca_transform_csr_##SUF(h, x.nrows, x.ncols, x.nnz, x.row_offsets, x.col_indices, x.values, o); } \
+    static sapca_status fit_transform(sapca_handle h, const CsrRef<T>& x, T* o) { return sapca_fit_transform_csr_##SUF(h, x.nrows, x.ncols, x.nnz, x.row_offsets, x.col_indices, x.values, o); } \
+    static sapca_status importances(sapca_handle h, T* o, size_t c) { return sapca_get_feature_importances_##SUF(h, o, c); } \
+    static sapca_status ratio(sapca_handle h, T* o, size_t c) { return sapca_get_explained_variance_ratio_##SUF(h, o, c); } \
+    static sapca_status cumulative(sapca_handle h, T* o, size_t c) { return sapca_get_cumulative_explained_variance_ratio_##SUF(h, o, c); } \
+  };
+SAPCA_ABI(f32, float)
+SAPCA_ABI(f64, double)
+#undef SAPCA_ABI
+
+template <typename T>
+class SparsePCA {
+ public:
+  SparsePCA(size_t n_components, T alpha, T tolerance, uint32_t seed, bool center, bool verbose, SVDMethod m,
+            const std::vector<bool>* mask = nullptr)
+      : k_(n_components), mask_len_(mask ? mask->size() : 0), masked_(mask != nullptr) {
+    sapca_options o;
+    sapca_options_default(&o);
+    o.n_components = n_components; o.alpha = alpha; o.tolerance = tolerance; o.random_seed = seed;
+    o.center = center; o.verbose = verbose;
+    o.method = m.random ? SAPCA_RANDOM : SAPCA_LANCZOS;
+    o.n_oversamples = m.n_oversamples; o.n_power_iterations = m.n_power_iterations; o.normalizer = (int32_t)m.normalizer;
+    sapca_status st = sapca_create(&o, &h_);
+    if (st != SAPCA_OK) throw Error(st, sapca_last_error(nullptr));
+    if (mask && !mask->empty()) {
+      std::vector<uint8_t> b(mask->begin(), mask->end());
+      check(sapca_set_mask(h_, b.data(), b.size()));
+    }
+  }
+  ~SparsePCA() { sapca_destroy(h_); }
+  SparsePCA(const SparsePCA&) = delete;
+  SparsePCA& operator=(const SparsePCA&) = delete;
+
+  SparsePCA& fit(const CsrRef<T>& x) { mask_check(x); check(Abi<T>::fit(h_, x)); return *this; }
+  std::vector<T> transform(const CsrRef<T>& x) const {                     // m x k row-major
+    mask_check(x);
+    std::vector<T> out(x.nrows * k_);
+    check(Abi<T>::transform(h_, x, out.data()));
+    return out;
+  }
+  std::vector<T> fit_transform(const CsrRef<T>& x) {
+    mask_check(x);
+    std::vector<T> out(x.nrows * k_);
+    check(Abi<T>::fit_transform(h_, x, out.data()));
+    return out;
+  }
+  std::vector<T> feature_importances() const {                             // k x n_used row-major
+    uint64_t k, nu, nc;
+    check(sapca_get_dims(h_, &k, &nu, &nc));
+    std::vector<T> out(k * nu);
+    check(Abi<T>::importances(h_, out.data(), out.size()));
+    return out;
+  }
+  std::vector<T> explained_variance_ratio() const { return vec(&Abi<T>::ratio); }
+  std::vector<T> cumulative_explained_variance_ratio() const { return vec(&Abi<T>::cumulative); }
+  sapca_handle handle() const { return h_; }
+
+ private:
+  void check(sapca_status st) const { if (st != SAPCA_OK) throw Error(st, sapca_last_error(h_)); }
+  void mask_check(const CsrRef<T>& x) const {   // the reference rejects any mismatch, an empty mask included (masked :258-262)
+    if (masked_ && x.ncols != mask_len_)
+      throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
+  }
+  std::vector<T> vec(sapca_status (*get)(sapca_handle, T*, size_t)) const {
+    uint64_t k, nu, nc;
+    check(sapca_get_dims(h_, &k, &nu, &nc));
+    std::vector<T> out(k);
+    check(get(h_, out.data(), out.size()));
+    return out;
+  }
+  sapca_handle h_ = nullptr;
+  size_t k_, mask_len_;
+  bool masked_;
+};
+
+// SparsePCABuilder<T> (sparse/mod.rs:375-484) and MaskedSparsePCABuilder<T> (sparse_masked/mod.rs:37-160)
+template <typename T, bool Masked>
+class BuilderT {
+ public:
+  BuilderT& n_components(size_t n) { k_ = n; return *this; }
+  BuilderT& alpha(T a) { alpha_ = a; return *this; }
+  BuilderT& tolerance(T t) { tol_ = t; return *this; }
+  BuilderT& random_seed(uint32_t s) { seed_ = s; return *this; }
+  BuilderT& center(bool c) { center_ = c; return *this; }
+  BuilderT& verbose(bool v) { verbose_ = v; return *this; }
+  BuilderT& svd_method(SVDMethod m) { method_ = m; return *this; }
+  BuilderT& mask(std::vector<bool> m) { static_assert(Masked, "mask() belongs to MaskedSparsePCABuilder"); mask_ = std::move(m); return *this; }
+  SparsePCA<T>* build() const { return new SparsePCA<T>(k_, alpha_, tol_, seed_, center_, verbose_, method_, Masked ? &mask_ : nullptr); }
+
+ private:
+  size_t k_ = 50; T alpha_ = 1; T tol_ = (T)1e-6; uint32_t seed_ = 42; bool center_ = true, verbose_ = false;   // :392-401
+  SVDMethod method_{};
+  std::vector<bool> mask_;
+};
+template <typename T> using SparsePCABuilder = BuilderT<T, false>;
+template <typename T> using MaskedSparsePCABuilder = BuilderT<T, true>;
+
+}  // namespace sapca

@@ -1,0 +1,86 @@
+//! Raw bindings to `include/sapca.h` (ABI version 1).  UNTESTED SOURCE: written against the header,
+//! never compiled in the build image (no rustc).  One `extern "C"` item per header declaration that
+//! the safe wrapper uses; the `_f64` twins mirror the `_f32` ones.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct sapca_handle_s {
+    _private: [u8; 0],
+}
+pub type sapca_handle = *mut sapca_handle_s;
+
+pub const SAPCA_OK: c_int = 0;
+pub const SAPCA_ERR_ARG: c_int = 1;
+pub const SAPCA_ERR_MASK_LEN: c_int = 2;
+pub const SAPCA_ERR_NOT_FITTED: c_int = 3;
+pub const SAPCA_ERR_SVD: c_int = 4;
+pub const SAPCA_ERR_HIP: c_int = 5;
+pub const SAPCA_ERR_COMM: c_int = 6;
+pub const SAPCA_ERR_NOMEM: c_int = 7;
+
+pub const SAPCA_LANCZOS: i32 = 0;
+pub const SAPCA_RANDOM: i32 = 1;
+pub const SAPCA_NORM_QR: i32 = 0;
+pub const SAPCA_NORM_LU: i32 = 1;
+pub const SAPCA_NORM_NONE: i32 = 2;
+
+/// `sapca_options` (include/sapca.h): the builder fields of sparse/mod.rs:375-484.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct sapca_options {
+    pub struct_size: u32,
+    pub random_seed: u32,
+    pub n_components: u64,
+    pub alpha: f64,
+    pub tolerance: f64,
+    pub center: u8,
+    pub verbose: u8,
+    pub collect_timings: u8,
+    pub reserved0: u8,
+    pub method: i32,
+    pub n_oversamples: u64,
+    pub n_power_iterations: u64,
+    pub normalizer: i32,
+    pub transform_semantics: i32,
+    pub device_id: i32,
+    pub spmm_variant: i32,
+    pub stream: *mut c_void,
+}
+
+extern "C" {
+    pub fn sapca_options_default(o: *mut sapca_options);
+    pub fn sapca_abi_version() -> c_int;
+    pub fn sapca_create(opts: *const sapca_options, out: *mut sapca_handle) -> c_int;
+    pub fn sapca_destroy(h: sapca_handle);
+    pub fn sapca_last_error(h: sapca_handle) -> *const c_char;
+    pub fn sapca_set_mask(h: sapca_handle, mask: *const u8, len: usize) -> c_int;
+
+    // nalgebra_sparse::CsrMatrix<T>: row_offsets()/col_indices() are &[usize] == *const u64 on 64-bit targets
+    pub fn sapca_fit_csr_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                             col_indices: *const u64, values: *const f32) -> c_int;
+    pub fn sapca_fit_csr_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                             col_indices: *const u64, values: *const f64) -> c_int;
+    pub fn sapca_transform_csr_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                   col_indices: *const u64, values: *const f32, out: *mut f32) -> c_int;
+    pub fn sapca_transform_csr_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                   col_indices: *const u64, values: *const f64, out: *mut f64) -> c_int;
+    pub fn sapca_fit_transform_csr_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                       col_indices: *const u64, values: *const f32, out: *mut f32) -> c_int;
+    pub fn sapca_fit_transform_csr_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                       col_indices: *const u64, values: *const f64, out: *mut f64) -> c_int;
+
+    pub fn sapca_get_dims(h: sapca_handle, k: *mut u64, n_used: *mut u64, n_cols: *mut u64) -> c_int;
+    pub fn sapca_get_components_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
+    pub fn sapca_get_components_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+    pub fn sapca_get_explained_variance_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
+    pub fn sapca_get_explained_variance_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+    pub fn sapca_get_mean_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
+    pub fn sapca_get_mean_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+    pub fn sapca_get_explained_variance_ratio_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
+    pub fn sapca_get_explained_variance_ratio_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+    pub fn sapca_get_cumulative_explained_variance_ratio_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
+    pub fn sapca_get_cumulative_explained_variance_ratio_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+    pub fn sapca_get_feature_importances_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
+    pub fn sapca_get_feature_importances_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+}
