@@ -52,7 +52,7 @@ def cpu_baseline(name, n, density, k, p, q, seed, gen_device="cpu"):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     from sapca import synth
-    ms = 10000 if name != "small" else 5000
+    ms = 30000 if name != "small" else 5000
     try:
         share = len(os.sched_getaffinity(0))
     except AttributeError:
