@@ -100,59 +100,79 @@ gram_reduce_kernel(const double* __restrict__ slabs, int nslabs, int nt, int ld,
 }
 
 // ---------------------------------------------------------------- Cholesky + inverse
-// One workgroup, one thread per column, everything in LDS.  Row-by-row (left-looking) upper
-// Cholesky: R[k][j] = (G[k][j] - sum_{t<k} R[t][k] R[t][j]) / R[k][k]; every thread walks the same
-// t-loop, so R[t][k] is an LDS broadcast and R[t][j] is conflict-free.  R^-1 by back substitution,
-// again one column per thread, with the inverse parked in the unused strict lower triangle
-// (Rinv[t][j], t < j, lives at a[j][t]) and its diagonal in dinv[].  A pivot that falls below
-// 1e-13 of the panel's scale (rank-deficient panel) is replaced by that floor and counted in
-// *info; the direction it produces carries a ~zero singular value downstream.
-__global__ void __launch_bounds__(128)
+// One workgroup of 256 threads, everything in LDS (f64).
+//   Cholesky (upper, G = R^T R), right-looking: per pivot k one thread takes the square root, the
+//   row is scaled, and all 256 threads apply the rank-1 update to the trailing upper triangle on a
+//   16 x 16 thread grid (no integer division in the loop).
+//   R^-1 by back substitution: column j is owned by 4 consecutive lanes that split the inner dot
+//   product and combine with two DPP-class shuffles; the inverse is parked in the unused strict
+//   lower triangle (Rinv[t][j], t < j, lives at a[j][t]) and its diagonal in dinv[].
+// A pivot that falls below 1e-13 of the panel's scale (rank-deficient panel) is replaced by that
+// floor and counted in *info; the direction it produces carries a ~zero singular value downstream.
+__global__ void __launch_bounds__(256)
 chol_inv_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
                 int* __restrict__ info) {
   extern __shared__ double a[];  // l x (l+1) working copy + l diagonal inverses
   const int st = l + 1;
   double* dinv = a + (size_t)l * st;
   __shared__ int bad;
-  const int j = threadIdx.x;
-  if (j == 0) bad = 0;
-  for (int i = threadIdx.x; i < l * l; i += blockDim.x) a[(i / l) * st + (i % l)] = G[(i / l) * ld + (i % l)];
+  __shared__ double floor_s;
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
+  if (tid == 0) bad = 0;
+  for (int i = tid; i < l * l; i += blockDim.x) a[(i / l) * st + (i % l)] = G[(i / l) * ld + (i % l)];
   __syncthreads();
-  double scale = 0;
-  for (int i = 0; i < l; ++i) scale = fmax(scale, fabs(a[i * st + i]));
-  const double floor_ = scale * 1e-13 + 1e-300;
+  if (tid == 0) {
+    double scale = 0;
+    for (int i = 0; i < l; ++i) scale = fmax(scale, fabs(a[i * st + i]));
+    floor_s = scale * 1e-13 + 1e-300;
+  }
+  __syncthreads();
   for (int kk = 0; kk < l; ++kk) {
-    double v = 0;
-    if (j >= kk && j < l) {
-      v = a[kk * st + j];
-      for (int t = 0; t < kk; ++t) v -= a[t * st + kk] * a[t * st + j];
-    }
-    if (j == kk) {
-      if (!(v > floor_)) { v = floor_; bad += 1; }
+    if (tid == 0) {
+      double v = a[kk * st + kk];
+      if (!(v > floor_s)) { v = floor_s; bad += 1; }
       v = sqrt(v);
       a[kk * st + kk] = v;
       dinv[kk] = 1.0 / v;
     }
     __syncthreads();
-    if (j > kk && j < l) a[kk * st + j] = v * dinv[kk];
+    const double inv = dinv[kk];
+    for (int j = kk + 1 + tid; j < l; j += blockDim.x) a[kk * st + j] *= inv;
+    __syncthreads();
+    for (int i = kk + 1 + ti; i < l; i += 16) {
+      const double ri = a[kk * st + i];
+      for (int j = kk + 1 + tj; j < l; j += 16)
+        if (j >= i) a[i * st + j] -= ri * a[kk * st + j];
+    }
     __syncthreads();
   }
-  // x = column j of R^-1: x_j = 1/R_jj, x_i = -(sum_{i<t<=j} R[i][t] x_t) / R_ii
-  if (j < l) {
-    for (int i = j - 1; i >= 0; --i) {
-      double s = a[i * st + j] * dinv[j];
-      for (int t = i + 1; t < j; ++t) s += a[i * st + t] * a[j * st + t];
-      a[j * st + i] = -s * dinv[i];
+  // x = column j of R^-1: x_j = 1/R_jj, x_i = -(sum_{i<t<=j} R[i][t] x_t) / R_ii; 4 lanes per column
+  for (int j0 = 0; j0 < l; j0 += 64) {
+    const int j = j0 + (tid >> 2), part = tid & 3;
+    const bool live = j < l;
+    const int jj = live ? j : 0;
+    for (int i = l - 1; i >= 0; --i) {   // uniform trip count so that the shuffles stay converged
+      double s = 0;
+      if (live && i < jj) {
+        for (int t = i + 1 + part; t < jj; t += 4) s += a[i * st + t] * a[jj * st + t];
+        if (part == 0) s += a[i * st + jj] * dinv[jj];
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (live && i < jj && part == 0) a[jj * st + i] = -s * dinv[i];
+      // lanes of one column are in the same wave: the write above is visible to their next iteration
+      __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ld * ld; i += blockDim.x) {
+  for (int i = tid; i < ld * ld; i += blockDim.x) {
     const int r = i / ld, c2 = i % ld;
     const bool in = r < l && c2 < l;
     R[i] = (in && c2 >= r) ? a[r * st + c2] : 0.0;
     Rinv[i] = !in ? 0.0 : (c2 > r ? a[c2 * st + r] : (c2 == r ? dinv[r] : 0.0));
   }
-  if (j == 0 && bad) atomicAdd(info, bad);
+  if (tid == 0 && bad) atomicAdd(info, bad);
 }
 
 // ---------------------------------------------------------------- panel GEMM
@@ -401,7 +421,7 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_bytes = lds;
   }
-  hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(128), lds, s, G, l, ld, R, Rinv, info);
+  hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds, s, G, l, ld, R, Rinv, info);
   SAPCA_HIP(hipGetLastError());
 }
 

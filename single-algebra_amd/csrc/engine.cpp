@@ -197,7 +197,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 // R10: PowerIterationNormalizer on a rows x ld panel (CholeskyQR, f64 Gram on MFMA).
 // ------------------------------------------------------------------------------------------
 template <typename T>
-void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2) {
+void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2,
+                          int passes_hint) {
   if (normalizer == SAPCA_NORM_NONE) return;
   hipStream_t s = h.stream;
   Scope sc(h, C_ORTHO);
@@ -207,8 +208,11 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
   double* Rtmp = base + (size_t)2 * ld * ld;
   int* info = reinterpret_cast<int*>(base + (size_t)6 * 128 * 128);
   // QR -> CholeskyQR2 (orthonormal to working precision); LU -> one pass: a well-conditioned
-  // basis of the same span, which is all the reference's LU normaliser provides.
-  const int passes = normalizer == SAPCA_NORM_QR ? 2 : 1;
+  // basis of the same span, which is all the reference's LU normaliser provides.  Between power
+  // iterations only the span matters (the next sweep re-mixes the basis), so the intermediate QR
+  // normalisations run the single pass too (`passes_hint` = 1); the final range basis Q and the
+  // factorisation of B^T always get both passes.
+  const int passes = passes_hint > 0 ? passes_hint : (normalizer == SAPCA_NORM_QR ? 2 : 1);
   for (int pass = 0; pass < passes; ++pass) {
     k::gram(P, rows, ld, G, h.scratch2, s);
     if (sharded && h.comm.active()) h.comm.allreduce(G, (uint64_t)ld * ld, 1, s);
@@ -284,9 +288,9 @@ void Engine<T>::fit_randomized(H& h) {
 
   for (int it = 0; it < q; ++it) {
     sweep_A();
-    normalize(h, Y, m, l, ld, norm, true, nullptr, nullptr);
+    normalize(h, Y, m, l, ld, norm, true, nullptr, nullptr, 1);
     sweep_At();
-    normalize(h, X, n_used, l, ld, norm, false, nullptr, nullptr);
+    normalize(h, X, n_used, l, ld, norm, false, nullptr, nullptr, 1);
   }
   sweep_A();
   normalize(h, Y, m, l, ld, SAPCA_NORM_QR, true, nullptr, nullptr);  // Q = qr(Y): always orthonormal

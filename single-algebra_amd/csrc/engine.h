@@ -85,7 +85,8 @@ struct Engine {
   static void fit_lanczos(H& h);
   // normaliser on a rows x ld panel; R_out (ld x ld f64 device, may be null) receives the
   // accumulated upper factor of the last CholeskyQR2.
-  static void normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2);
+  static void normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2,
+                        int passes_hint = 0);
   static CsrView<T> view(const H::RawCsr& r) {
     CsrView<T> v;
     v.rows = r.rows; v.cols = r.cols; v.nnz = r.nnz;
