@@ -92,14 +92,18 @@ tiled_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ i
                   const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, int tc,
                   int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ wave_off,
                   Ent* __restrict__ ent) {
-  extern __shared__ uint32_t run[];  // [WAVES][nct] padded length of the wave's earlier rows, per tile
+  extern __shared__ uint32_t run[];  // [WAVES][nct] next free slot of this wave in every tile's chunk,
+                                     // relative to the block's first chunk (one LDS read per entry)
   const int rb = blockIdx.x;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int rpw = (nrows + WAVES - 1) / WAVES;
-  uint32_t* myrun = run + wave * nct;
-  for (int t = lane; t < nct; t += WAVE) myrun[t] = 0;
+  uint32_t* mybase = run + wave * nct;
+  const int64_t block_base = chunk_off[(int64_t)rb * nct];
+  for (int t = lane; t < nct; t += WAVE)
+    mybase[t] = (uint32_t)(chunk_off[(int64_t)rb * nct + t] - block_base) + wave_off[((int64_t)rb * nct + t) * WAVES + wave];
   __builtin_amdgcn_wave_barrier();
+  Ent* __restrict__ out = ent + block_base;
   const int lr0 = wave * rpw, lr1 = min(nrows, lr0 + rpw);
   for (int lr = lr0; lr < lr1; ++lr) {
     const int64_t r = row0 + lr;
@@ -108,17 +112,15 @@ tiled_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ i
     for (int64_t e = e0 + lane; e < e1; e += WAVE) {
       const int c = idx[e];
       const int t = c / tc;
-      const int64_t dst = chunk_off[(int64_t)rb * nct + t] + wave_off[((int64_t)rb * nct + t) * WAVES + wave] + myrun[t] +
-                          (uint32_t)((e - e0) - sg[t]);
       Ent x;
       x.off = (uint32_t)(c - t * tc) * (uint32_t)ldp_bytes;
       x.val = val[e];
-      ent[dst] = x;
+      out[mybase[t] + (uint32_t)((e - e0) - sg[t])] = x;
     }
-    __builtin_amdgcn_wave_barrier();  // the wave's reads of myrun (above) precede its update (below)
+    __builtin_amdgcn_wave_barrier();  // the wave's reads of mybase (above) precede its update (below)
     for (int t = lane; t < nct; t += WAVE) {
       const int len = sg[t + 1] - sg[t];
-      myrun[t] += (uint32_t)((len + PAD - 1) / PAD * PAD);
+      mybase[t] += (uint32_t)((len + PAD - 1) / PAD * PAD);
     }
     __builtin_amdgcn_wave_barrier();
   }
