@@ -88,7 +88,7 @@ struct TiledOp {
   const void* ent = nullptr;           // {u32 lds byte offset, f32 value}
 };
 struct TiledBuffers {
-  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc;
+  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run;
 };
 
 struct Stream {

@@ -91,14 +91,15 @@ __global__ void __launch_bounds__(WAVES * WAVE)
 tiled_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                   const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, int tc,
                   int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ wave_off,
-                  Ent* __restrict__ ent) {
+                  Ent* __restrict__ ent, uint32_t* __restrict__ run_global) {
   extern __shared__ uint32_t run[];  // [WAVES][nct] next free slot of this wave in every tile's chunk,
                                      // relative to the block's first chunk (one LDS read per entry)
   const int rb = blockIdx.x;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int rpw = (nrows + WAVES - 1) / WAVES;
-  uint32_t* mybase = run + wave * nct;
+  // many column tiles (A^T of a tall matrix): the table does not fit LDS and lives in HBM/L2 instead
+  uint32_t* mybase = run_global ? run_global + ((size_t)rb * WAVES + wave) * nct : run + wave * nct;
   const int64_t block_base = chunk_off[(int64_t)rb * nct];
   for (int t = lane; t < nct; t += WAVE)
     mybase[t] = (uint32_t)(chunk_off[(int64_t)rb * nct + t] - block_base) + wave_off[((int64_t)rb * nct + t) * WAVES + wave];
@@ -389,14 +390,18 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   }
   Ent* d_ent = reinterpret_cast<Ent*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(Ent)));
   SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
-  const size_t lds = (size_t)waves * nct * sizeof(uint32_t);
-  SAPCA_CHECK(lds <= 64 * 1024, SAPCA_ERR_ARG, "tiled sweep: too many column tiles");
+  size_t lds = (size_t)waves * nct * sizeof(uint32_t);
+  uint32_t* run_global = nullptr;
+  if (lds > 48 * 1024) {
+    run_global = buf.run.as<uint32_t>((size_t)nrb * waves * nct);
+    lds = 0;
+  }
   if (slots == 2)
     hipLaunchKernelGGL((tiled_fill_kernel<16, 2>), dim3((unsigned)nrb), dim3(16 * WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
-                       d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent);
+                       d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   else
     hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)nrb), dim3(8 * WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
-                       d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent);
+                       d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   SAPCA_HIP(hipGetLastError());
   op.rows = A.rows; op.cols = A.cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots;
