@@ -39,6 +39,10 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int RW = 32;            // max rows per wave (register accumulators)
+#ifndef SAPCA_RW2
+#define SAPCA_RW2 32
+#endif
+constexpr int RW2 = SAPCA_RW2;   // rows per wave of the default (2 lane groups, LDP 64) configuration
 constexpr int BLOCK_ROWS = 512;   // stride of the per-(block, tile) step table; max rows per block
 // lane groups ("slots") per wave: 2 half-waves (16 waves/workgroup, 512 rows) or 4 quarter-waves
 // (8 waves/workgroup, 256 rows, half the LDS instructions per entry)
@@ -202,7 +206,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
   constexpr int WAVES = waves_for(SLOTS), THREADS = WAVES * WAVE, PAD = SLOTS;
   constexpr int LPE = WAVE / SLOTS;   // lanes that cover one panel row
   constexpr int VPL = LDP / LPE;      // panel values per lane
-  constexpr int RWK = (SLOTS == 2 && LDP == 128) ? RW / 2 : RW;   // rows per wave: the accumulators must fit the VGPR budget
+  constexpr int RWK = (SLOTS == 2 && LDP == 128) ? RW / 2 : (SLOTS == 2 ? RW2 : RW);   // rows per wave: the accumulators must fit the VGPR budget
   constexpr int NP_TILE = np_tile(THREADS), NP_STAGE = np_stage(THREADS);
   using LN = Lane<VPL>;
   using V = typename LN::V;
@@ -223,20 +227,32 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
   for (int i = 0; i < RWK; ++i) acc[i] = V(0.f);
 
   v4f pt[NP_TILE], ps[NP_STAGE];
+  // per-tile bookkeeping of this wave (step counts of its rows, start of its entries), fetched one
+  // tile ahead and BEFORE the bulk prefetch: vmcnt retires in order, so a small load issued after
+  // the prefetch would make its first use wait for the whole prefetch
+  int cnt_next = 0;
+  unsigned woff_next = 0;
+#define SAPCA_BOOKKEEPING(CT)                                                                      \
+  {                                                                                                \
+    const int64_t cidx_ = (int64_t)rb * nct + (CT);                                                \
+    cnt_next = lane < my_rows ? (int)steps[cidx_ * BLOCK_ROWS + wave * rpw + lane] : 0;            \
+    woff_next = wave_off[cidx_ * WAVES + wave];                                                    \
+  }
+  if (ct0 < ct1) SAPCA_BOOKKEEPING(ct0)
   if (PREFETCH && ct0 < ct1) SAPCA_PREFETCH(ct0)
   for (int ct = ct0; ct < ct1; ++ct) {
-    const int64_t cidx = (int64_t)rb * nct + ct;
     __syncthreads();  // the previous tile's readers are done
     if (!PREFETCH && (!(mode & 2) || ct == ct0)) SAPCA_PREFETCH(ct)
     store_regs<NP_TILE, THREADS>(pt, tile, TILE_BYTES);
     store_regs<NP_STAGE, THREADS>(ps, stage, STAGE_BYTES);
     __syncthreads();
+    const int cnt_v = cnt_next;
+    const unsigned woff = woff_next;
+    if (ct + 1 < ct1) SAPCA_BOOKKEEPING(ct + 1)
     if (PREFETCH && ct + 1 < ct1) SAPCA_PREFETCH(ct + 1)
     if (mode & 1) continue;
     if (my_rows > 0) {
-      int cnt_v = 0;
-      if (lane < my_rows) cnt_v = steps[cidx * BLOCK_ROWS + wave * rpw + lane];
-      const char* sl = stage + (size_t)wave_off[cidx * WAVES + wave] * 8 + half * 8;
+      const char* sl = stage + (size_t)woff * 8 + half * 8;
 #pragma unroll
       for (int rr = 0; rr < RWK; ++rr) {
         int n = __builtin_amdgcn_readlane(cnt_v, rr);
@@ -296,6 +312,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 }
 
 #undef SAPCA_PREFETCH
+#undef SAPCA_BOOKKEEPING
 
 template <int LDP, int SLOTS, bool PREFETCH>
 void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
@@ -326,7 +343,7 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
   const int slots = (ldp == 64 && slots_env == 4) ? 4 : 2;
   const int waves = waves_for(slots);
-  const int block_rows = waves * ((slots == 2 && ldp == 128) ? RW / 2 : RW);
+  const int block_rows = waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
   int64_t nrb = (A.rows + block_rows - 1) / block_rows;
   int nsplit = 1;
   if (nrb >= 192) {
