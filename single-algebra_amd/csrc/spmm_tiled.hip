@@ -89,21 +89,23 @@ tiled_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ 
   if (lr < WAVES && lr * rpw >= nrows) wave_off[(int64_t)blockIdx.x * WAVES + lr] = scan[BLOCK_ROWS - 1];
 }
 
-// one block per row block; wave w copies its rows' entries into every column tile's chunk
+// one single-wave workgroup per (row block, wave): it copies that wave's rows' entries into every
+// column tile's chunk (one wave per workgroup so that operators with few row blocks -- A^T -- still
+// spread over all CUs)
 template <int WAVES, int PAD>
-__global__ void __launch_bounds__(WAVES * WAVE)
+__global__ void __launch_bounds__(WAVE)
 tiled_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                   const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, int tc,
                   int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ wave_off,
                   Ent* __restrict__ ent, uint32_t* __restrict__ run_global) {
-  extern __shared__ uint32_t run[];  // [WAVES][nct] next free slot of this wave in every tile's chunk,
+  extern __shared__ uint32_t run[];  // [nct] next free slot of this wave in every tile's chunk,
                                      // relative to the block's first chunk (one LDS read per entry)
-  const int rb = blockIdx.x;
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int rb = blockIdx.x / WAVES;
+  const int wave = blockIdx.x % WAVES, lane = threadIdx.x;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int rpw = (nrows + WAVES - 1) / WAVES;
   // many column tiles (A^T of a tall matrix): the table does not fit LDS and lives in HBM/L2 instead
-  uint32_t* mybase = run_global ? run_global + ((size_t)rb * WAVES + wave) * nct : run + wave * nct;
+  uint32_t* mybase = run_global ? run_global + (size_t)blockIdx.x * nct : run;
   const int64_t block_base = chunk_off[(int64_t)rb * nct];
   for (int t = lane; t < nct; t += WAVE)
     mybase[t] = (uint32_t)(chunk_off[(int64_t)rb * nct + t] - block_base) + wave_off[((int64_t)rb * nct + t) * WAVES + wave];
@@ -349,8 +351,11 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   if (nrb >= 192) {
     nrb = round_up(nrb, 256);
   } else {
-    nsplit = (int)std::min<int64_t>(nct, (512 + nrb - 1) / nrb);
-    if (nsplit < 1) nsplit = 1;
+    // few row blocks (A^T): split the tile range so that (blocks x splits) lands just under a
+    // multiple of the 256 CUs -- one workgroup per CU per round, no half-empty last round
+    nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, 512 / nrb));
+    const int64_t nrb_fit = 512 / nsplit;
+    if (nrb_fit >= nrb && nrb_fit <= A.rows) nrb = nrb_fit;
   }
   int32_t* d_seg = buf.seg.as<int32_t>((size_t)A.rows * (nct + 1));
   build_tile_index(A, tc, nct, d_seg, s);
@@ -407,17 +412,17 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   }
   Ent* d_ent = reinterpret_cast<Ent*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(Ent)));
   SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
-  size_t lds = (size_t)waves * nct * sizeof(uint32_t);
+  size_t lds = (size_t)nct * sizeof(uint32_t);
   uint32_t* run_global = nullptr;
   if (lds > 48 * 1024) {
     run_global = buf.run.as<uint32_t>((size_t)nrb * waves * nct);
     lds = 0;
   }
   if (slots == 2)
-    hipLaunchKernelGGL((tiled_fill_kernel<16, 2>), dim3((unsigned)nrb), dim3(16 * WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+    hipLaunchKernelGGL((tiled_fill_kernel<16, 2>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   else
-    hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)nrb), dim3(8 * WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+    hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)(nrb * 8)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   SAPCA_HIP(hipGetLastError());
   op.rows = A.rows; op.cols = A.cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
