@@ -71,6 +71,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("SAPCA_NO_AUTOBUILD"):
+        # building the product is not a fallback: same sources, same gfx950 target
+        import shutil
+        import subprocess
+        if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+            subprocess.call(["make", "-C", os.path.normpath(os.path.join(_HERE, "..", "..")), "-j", "8"])
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C single-algebra_amd` "

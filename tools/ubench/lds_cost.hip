@@ -24,13 +24,18 @@ __global__ void __launch_bounds__(1024) k(float* out, int iters) {
     if (MODE == 4) ad[u] = (base + u * 32 + (lane >> 4) * 8) & 0x1fff8;
     if (MODE == 5) ad[u] = (base + u * 32 + (lane >> 5) * 16) & 0x1fff0;
     if (MODE == 6) ad[u] = (base + u * 8) & 0x1fff8;
+    if (MODE == 7) ad[u] = (base + u * 640 + lane * 4) & 0x1fffc;                                   // atomic add, 64 lanes contiguous
+    if (MODE == 8) ad[u] = (base + u * 640 + (lane >> 5) * 2048 + (lane & 31) * 4) & 0x1fffc;       // atomic add, 2 rows x 128 B
+    if (MODE == 9) ad[u] = (base + u * 640 + (lane >> 5) * 2048 + (lane & 31) * 8) & 0x1fff8;       // ds_add_f64? (pk) 2 rows x 256 B
     asm volatile("" : "+v"(ad[u]));
   }
   long long t0 = clock64();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (MODE == 2) { float w = *reinterpret_cast<const float*>(lds + ad[u]); asm volatile("" :: "v"(w)); }
+      if (MODE == 7 || MODE == 8) { atomicAdd(reinterpret_cast<float*>(lds + ad[u]), 1.0f); }
+      else if (MODE == 9) { atomicAdd(reinterpret_cast<double*>(lds + ad[u]), 1.0); }
+      else if (MODE == 2) { float w = *reinterpret_cast<const float*>(lds + ad[u]); asm volatile("" :: "v"(w)); }
       else if (MODE == 3 || MODE == 5) { v4f w = *reinterpret_cast<const v4f*>(lds + ad[u]); asm volatile("" :: "v"(w)); }
       else { v2f w = *reinterpret_cast<const v2f*>(lds + ad[u]); asm volatile("" :: "v"(w)); }
     }
@@ -62,5 +67,8 @@ int main() {
   run<4>("b64 entry (4 distinct addrs)", d, iters);
   run<5>("b128 entry (2 distinct addrs)", d, iters);
   run<6>("b64 full broadcast", d, iters);
+  run<7>("ds_add_f32 64 lanes contiguous", d, iters);
+  run<8>("ds_add_f32 2 rows x 128B", d, iters);
+  run<9>("ds_add_f64 2 rows x 256B", d, iters);
   return 0;
 }
