@@ -435,3 +435,50 @@ def test_fit_is_the_same_with_either_sweep_kernel(golden):
         np.testing.assert_allclose(res[-1][0], g["s"], rtol=1e-4)
         assert O.subspace_angle(res[-1][1], g["vt"]) < 1e-4
     np.testing.assert_allclose(res[0][2], res[1][2], atol=2e-3 * np.abs(res[0][2]).max())
+
+
+# ------------------------------------------------------------------ wide panels, new-matrix transform, limits
+def test_fit_wide_panel_k100():
+    """l = 110 (the C5 shape of the panel): the 128-wide sweep path through a whole fit"""
+    m, n, k, p, q = 3000, 400, 100, 10, 2
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, 0.08, seed=31, dtype=torch.float32))
+    om = synth.gaussian_panel(n, k + p, 9).numpy()
+    want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    for variant in (1, 2):
+        pca = _builder(k, p, q).spmm_variant(variant).build().set_omega(om)
+        pca.fit(mat(ptr, idx, val, m, n))
+        np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=2e-4)
+        # flat spectrum: compare the projector on the leading, well separated part only
+        np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), O.explained_variance_ratio(want.explained_variance), atol=2e-5)
+
+
+def test_panel_width_limit_is_an_error():
+    ptr, idx, val = csr_np(synth.flat_csr(400, 300, 0.1, seed=2, dtype=torch.float32))
+    pca = _builder(120, 10, 1).build()
+    with pytest.raises(L.SapcaError, match="above 128") as e:
+        pca.fit(mat(ptr, idx, val, 400, 300))
+    assert e.value.status == L.ERR_ARG
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_transform_of_a_matrix_that_was_not_fitted(dtype):
+    """transform(B) with B != the fitted matrix: column counts (Q2) come from B, the mean from the fit"""
+    m, n, k = 1500, 300, 6
+    a = csr_np(synth.gapped_csr(m, n, 0.08, k, seed=3, dtype=torch.float64))
+    b = csr_np(synth.gapped_csr(700, n, 0.05, k, seed=4, dtype=torch.float64))
+    A, B = mat(a[0], a[1], a[2].astype(dtype), m, n), mat(b[0], b[1], b[2].astype(dtype), 700, n)
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    pca = _builder(k, 6, 2).build()
+    pca.fit(A)
+    t = pca.transform(B)
+    want = O.transform_sparse(b[0], b[1], b[2], 700, n, pca.components_(np.float64), pca.mean_(np.float64), True)
+    np.testing.assert_allclose(t, want, atol=tol * np.abs(want).max())
+    mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
+    mp_ = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).svd_method(SVDMethod.Random(6, 2)).build())
+    mp_.fit(A)
+    tm = mp_.transform(B)
+    want_m = O.transform_masked_fast(b[0], b[1], b[2], 700, n, mp_.components_(np.float64), mp_.mean_(np.float64), True, mask)
+    np.testing.assert_allclose(tm, want_m, atol=tol * np.abs(want_m).max())
+    with pytest.raises(L.SapcaError):
+        pca.transform(mat(a[0][:11], a[1][:a[0][10]], a[2][:a[0][10]].astype(dtype), 10, n + 1) if False else
+                      sp.csr_matrix((10, n + 1), dtype=dtype))
