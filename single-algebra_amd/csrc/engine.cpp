@@ -177,12 +177,12 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
                                           std::min<int64_t>((int64_t)h.m_global, n_used));
       if (l >= 1 && l <= 128) {
         const int ldp = l <= 64 ? 64 : 128;
-        // The staged sweep refills a 96 KiB panel tile per (512-row block, column tile) chunk; it only
+        // The staged sweep refills an 80 KiB panel tile per (512-row block, column tile) chunk; it only
         // beats the row-gather kernel when a chunk carries enough entries to amortise that fill
-        // (measured: 3.9k entries/chunk -> 1.7x faster, 0.6k -> no gain and 4x the prepare time).
-        const double tile_cols = 96.0 * 1024.0 / (ldp * 4.0);
-        const double chunks = std::ceil((double)m / 512.0) * std::ceil((double)n_used / tile_cols);
-        const bool dense_enough = (double)h.a_used.nnz >= 1536.0 * chunks;
+        // (measured: 64 tile bytes per entry or less -> clearly faster; 164 -> no gain, 4x the prepare time).
+        const double tile_bytes = 80.0 * 1024.0, block_rows = ldp == 64 ? 512.0 : 256.0;
+        const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_used * ldp * 4.0 / tile_bytes);
+        const bool dense_enough = (double)h.a_used.nnz * 64.0 >= chunks * tile_bytes;
         const bool want = h.opt.spmm_variant == 2 || dense_enough;
         const bool ok_a = want && k::build_tiled(view(h.a_used), ldp, h.tiled_a, h.tb_a, s);
         const bool ok_at = ok_a && k::build_tiled(view(h.at_used), ldp, h.tiled_at, h.tb_at, s);

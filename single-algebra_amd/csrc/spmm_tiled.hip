@@ -42,6 +42,15 @@ constexpr int RW = 32;            // max rows per wave (register accumulators)
 #ifndef SAPCA_RW2
 #define SAPCA_RW2 32
 #endif
+#ifndef SAPCA_PIPE
+#define SAPCA_PIPE 0
+#endif
+#ifndef SAPCA_PADSTEPS
+#define SAPCA_PADSTEPS 1   // row segments of the two-lane-group format are padded to this many steps
+#endif
+#ifndef SAPCA_ABL
+#define SAPCA_ABL 0   // compile-time ablations of the sweep's inner loop (tools/abl_build.sh); 0 in the product
+#endif
 constexpr int RW2 = SAPCA_RW2;   // rows per wave of the default (2 lane groups, LDP 64) configuration
 constexpr int BLOCK_ROWS = 512;   // stride of the per-(block, tile) step table; max rows per block
 // lane groups ("slots") per wave: 2 half-waves (16 waves/workgroup, 512 rows) or 4 quarter-waves
@@ -74,7 +83,7 @@ tiled_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ 
     nb = (uint32_t)((len + PAD - 1) / PAD);
     padded = nb * PAD;
   }
-  steps[(int64_t)blockIdx.x * BLOCK_ROWS + lr] = (uint8_t)nb;
+  steps[(int64_t)blockIdx.x * BLOCK_ROWS + lr] = (uint8_t)(WAVES == 16 ? nb * SAPCA_PADSTEPS : nb);
   scan[lr] = padded;
   __syncthreads();
   for (int off = 1; off < BLOCK_ROWS; off <<= 1) {   // inclusive prefix (Hillis-Steele)
@@ -158,13 +167,72 @@ template <int VPL, int PAD, int U>
 __device__ __forceinline__ void steps_batch(typename Lane<VPL>::V& acc, const char* stage_lane, const char* tile_lane) {
   typedef unsigned int u2 __attribute__((ext_vector_type(2)));
   u2 e[U];
+#if SAPCA_ABL & 2   // ablation: no entry reads (one fixed entry held in registers, no extra VALU)
+  {
+    u2 f;
+    f.x = (unsigned)(size_t)stage_lane & 0xff00u;
+    f.y = 0x3f800000u;
+    asm volatile("" : "+v"(f));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      e[u] = f;
+      e[u].x += u * 256;   // folds into the ds_read offset field
+    }
+  }
+#else
 #pragma unroll
   for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const u2*>(stage_lane + u * (PAD * 8));
+#endif
   typename Lane<VPL>::V w[U];
+#if SAPCA_ABL & 1   // ablation: no panel gathers
+#pragma unroll
+  for (int u = 0; u < U; ++u) w[u] = typename Lane<VPL>::V(__uint_as_float(e[u].x));
+#else
 #pragma unroll
   for (int u = 0; u < U; ++u) w[u] = Lane<VPL>::load(tile_lane + e[u].x);
+#endif
+#if SAPCA_ABL & 4   // ablation: no FMAs
+#pragma unroll
+  for (int u = 0; u < U; ++u) asm volatile("" ::"v"(w[u]), "v"(e[u].y));
+#else
 #pragma unroll
   for (int u = 0; u < U; ++u) acc += __uint_as_float(e[u].y) * w[u];
+#endif
+}
+
+// Pipelined variant for two lane groups: rows are walked in static pairs (two accumulators), the
+// pair's steps form ONE stream cut into batches of up to 4, and the entries of the next batch are
+// read while the current batch's panel gathers are in flight, so a batch costs one LDS round trip
+// instead of two.  `e` always holds the entries of the 4 steps at `sl`; the first k consumed steps
+// belong to acc0, the rest to acc1 (k is wave-uniform).
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_entries4(u2v (&e)[4], const char* p) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const u2v*>(p + u * 16);
+}
+template <int U>
+__device__ __forceinline__ void pair_batch(v2f& acc0, v2f& acc1, u2v (&e)[4], const char*& sl, const char* tl, int k) {
+  v2f w[U];
+  float a[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const v2f*>(tl + e[u].x);
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = __uint_as_float(e[u].y);
+  sl += U * 16;
+  load_entries4(e, sl);
+  if (k >= U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc0 += a[u] * w[u];
+  } else if (k <= 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc1 += a[u] * w[u];
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < k) acc0 += a[u] * w[u];
+      else acc1 += a[u] * w[u];
+    }
+  }
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -243,18 +311,37 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
   if (ct0 < ct1) SAPCA_BOOKKEEPING(ct0)
   if (PREFETCH && ct0 < ct1) SAPCA_PREFETCH(ct0)
   for (int ct = ct0; ct < ct1; ++ct) {
-    __syncthreads();  // the previous tile's readers are done
-    if (!PREFETCH && (!(mode & 2) || ct == ct0)) SAPCA_PREFETCH(ct)
-    store_regs<NP_TILE, THREADS>(pt, tile, TILE_BYTES);
-    store_regs<NP_STAGE, THREADS>(ps, stage, STAGE_BYTES);
-    __syncthreads();
+    if (!(mode & 8) || ct == ct0) {
+      __syncthreads();  // the previous tile's readers are done
+      if (!PREFETCH && (!(mode & 2) || ct == ct0)) SAPCA_PREFETCH(ct)
+      store_regs<NP_TILE, THREADS>(pt, tile, TILE_BYTES);
+      store_regs<NP_STAGE, THREADS>(ps, stage, STAGE_BYTES);
+      __syncthreads();
+    }
     const int cnt_v = cnt_next;
     const unsigned woff = woff_next;
-    if (ct + 1 < ct1) SAPCA_BOOKKEEPING(ct + 1)
-    if (PREFETCH && ct + 1 < ct1) SAPCA_PREFETCH(ct + 1)
+    if (ct + 1 < ct1 && !(mode & 8)) SAPCA_BOOKKEEPING(ct + 1)
+    if (PREFETCH && ct + 1 < ct1 && !(mode & 10)) SAPCA_PREFETCH(ct + 1)
     if (mode & 1) continue;
     if (my_rows > 0) {
       const char* sl = stage + (size_t)woff * 8 + half * 8;
+      if constexpr (SLOTS == 2 && LDP == 64 && SAPCA_PIPE) {
+        u2v e[4];
+        load_entries4(e, sl);
+#pragma unroll
+        for (int rr = 0; rr < RWK; rr += 2) {
+          int k = __builtin_amdgcn_readlane(cnt_v, rr);
+          int n = k + __builtin_amdgcn_readlane(cnt_v, rr + 1);
+          while (n >= 4) {
+            pair_batch<4>(acc[rr], acc[rr + 1], e, sl, tl, k);
+            k -= 4;
+            n -= 4;
+          }
+          if (n == 3) pair_batch<3>(acc[rr], acc[rr + 1], e, sl, tl, k);
+          else if (n == 2) pair_batch<2>(acc[rr], acc[rr + 1], e, sl, tl, k);
+          else if (n == 1) pair_batch<1>(acc[rr], acc[rr + 1], e, sl, tl, k);
+        }
+      } else
 #pragma unroll
       for (int rr = 0; rr < RWK; ++rr) {
         int n = __builtin_amdgcn_readlane(cnt_v, rr);
@@ -268,7 +355,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
           sl += 2 * PAD * 8;
           n -= 2;
         }
-        if (n) {
+        if ((SLOTS != 2 || SAPCA_PADSTEPS < 2) && n) {
           steps_batch<VPL, PAD, 1>(acc[rr], sl, tl);
           sl += PAD * 8;
         }
@@ -316,6 +403,311 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 #undef SAPCA_PREFETCH
 #undef SAPCA_BOOKKEEPING
 
+// ------------------------------------------------------------------------ "quad" format and sweep
+// Second formulation of the staged sweep.  Measured on the first one (profiles/): a
+// SIMD retires about one instruction per 4-6 cycles whatever its kind, so the sweep time follows
+// the number of instructions per stored entry.  Here a wave is four groups of 16 lanes and every
+// group walks its OWN row (ds_read_b128: a lane holds 4 of the 64 panel columns, 8 of 128), so
+// one instruction stream advances four entries, there is no duplicate accumulator to reduce at
+// the end, and the accumulators of a 512-row block take 32 VGPRs instead of 64.  The four rows of
+// a quad advance in lockstep: the format pads every quad's segment in a tile to its longest row
+// (zero entries: offset 0, value 0).
+constexpr int QGROUPS = 4, QLANES = WAVE / QGROUPS, QWAVES = 16, QTHREADS = QWAVES * WAVE;
+constexpr int Q_TILE_BYTES = 80 * 1024;
+constexpr int Q_STAGE_BYTES = LDS_TOTAL - Q_TILE_BYTES - 1024;
+constexpr int Q_STAGE_ENTRIES = Q_STAGE_BYTES / 8 - WAVE;
+constexpr int Q_BLOCK_QUADS = BLOCK_ROWS / 4;   // stride of the per-chunk quad step table
+constexpr int q_rows_per_group(int ldp) { return ldp == 64 ? 8 : 4; }
+// quads (4 consecutive rows) of a block are dealt to its 16 waves in contiguous, balanced ranges
+__host__ __device__ inline int q_first(int wave, int nquads) { return wave * nquads / QWAVES; }
+
+// Column tiles of this format are INTERLEAVED: tile t holds the panel rows {c : c mod nct == t}, at
+// position c / nct.  Contiguous column ranges with their own density (gene modules, a dense band of
+// a cluster) are thereby spread over all tiles, every (row, tile) segment has about the same length,
+// the waves of a workgroup reach the per-tile barrier together and quads pad little.
+__device__ __forceinline__ void divmod_small(int c, int d, float inv, int& q, int& r) {   // c < 2^24
+  q = (int)((float)c * inv);
+  r = c - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
+// seg[r][t] = number of entries of row r in tiles < t (t = 0..nct): LDS histogram per row, one wave per row
+__global__ void __launch_bounds__(256)
+tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows, int nct, float inv_nct,
+                 int32_t* __restrict__ seg) {
+  extern __shared__ uint32_t hist_all[];
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  uint32_t* hist = hist_all + (size_t)wave * nct;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    for (int t = lane; t < nct; t += WAVE) hist[t] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    for (int64_t e = e0 + lane; e < e1; e += WAVE) {
+      int q, t;
+      divmod_small(idx[e], nct, inv_nct, q, t);
+      atomicAdd(&hist[t], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t carry = 0;
+    int32_t* out = seg + r * (nct + 1);
+    for (int t0 = 0; t0 < nct; t0 += WAVE) {
+      const int t = t0 + lane;
+      const uint32_t v = t < nct ? hist[t] : 0u;
+      uint32_t x = v;
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+      }
+      if (t < nct) out[t] = (int32_t)(carry + x - v);
+      carry += __shfl(x, WAVE - 1);
+    }
+    if (lane == 0) out[nct] = (int32_t)carry;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// one block per (row block, column tile): steps of every quad (= its longest row segment), entry
+// offset of every wave, chunk size
+__global__ void __launch_bounds__(BLOCK_ROWS)
+quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct,
+                  uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
+                  int64_t* __restrict__ chunk_size) {
+  __shared__ uint32_t scan[BLOCK_ROWS];
+  const int rb = blockIdx.x / nct, ct = blockIdx.x % nct;
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  const int nquads = (nrows + 3) / 4;
+  const int lr = threadIdx.x;   // local row; its quad is lr / 4
+  int len = 0;
+  if (lr < nrows) {
+    const int64_t r = row0 + lr;
+    len = seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
+  }
+  int qmax = max(len, __shfl_xor(len, 1));
+  qmax = max(qmax, __shfl_xor(qmax, 2));
+  const uint32_t padded = (lr & 3) == 0 ? (uint32_t)qmax * 4u : 0u;
+  if ((lr & 3) == 0) steps[(int64_t)blockIdx.x * Q_BLOCK_QUADS + lr / 4] = (uint16_t)qmax;
+  scan[lr] = padded;
+  __syncthreads();
+  for (int off = 1; off < BLOCK_ROWS; off <<= 1) {
+    uint32_t v = lr >= off ? scan[lr - off] : 0;
+    __syncthreads();
+    scan[lr] += v;
+    __syncthreads();
+  }
+  // [row block][quad][tile]: the builder reads one quad's offsets in all tiles contiguously
+  if ((lr & 3) == 0 && lr / 4 < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + lr / 4) * nct + ct] = scan[lr] - padded;
+  if (lr < QWAVES) {
+    const int first_row = 4 * q_first(lr, nquads);
+    wave_off[(int64_t)blockIdx.x * QWAVES + lr] = first_row > 0 ? scan[first_row - 1] : 0u;
+  }
+  if (lr == BLOCK_ROWS - 1) chunk_size[blockIdx.x] = scan[lr];
+}
+
+// one wave per row: the k-th entry (in column order) that the row has in tile t goes to slot
+// (k*4 + g) of its quad's segment in that tile's chunk (g = row mod 4 within the block)
+__global__ void __launch_bounds__(256)
+quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+                 int64_t rows, const int32_t* __restrict__ blk_row0, int nrb, int nct, float inv_nct, int ldp_bytes,
+                 const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off, Ent* __restrict__ ent) {
+  extern __shared__ uint32_t cnt_all[];   // per wave and tile: slot of the row's next entry (relative to the block's first chunk)
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  uint32_t* cnt = cnt_all + (size_t)wave * nct;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  int lo = 0, hi = nrb;   // row block: the last b with blk_row0[b] <= r
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)blk_row0[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int rb = lo;
+  const int lr = (int)(r - blk_row0[rb]);
+  const int qd = lr >> 2;
+  const uint32_t g = (uint32_t)(lr & 3);
+  const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
+  const uint32_t* __restrict__ qoff = quad_off + ((int64_t)rb * Q_BLOCK_QUADS + qd) * nct;
+  const int64_t block_base = coff[0];
+  for (int t = lane; t < nct; t += WAVE) cnt[t] = (uint32_t)(coff[t] - block_base) + qoff[t] + g;
+  __builtin_amdgcn_wave_barrier();
+  const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+  Ent* __restrict__ out = ent + block_base;
+  // batches of 64 entries in column order; within a batch the LDS atomic hands out the ranks of
+  // equal tiles (a fixed function of the input: the format is reproducible run to run)
+  for (int64_t eb = e0; eb < e1; eb += WAVE) {
+    const int64_t e = eb + lane;
+    if (e < e1) {
+      int i, t;
+      divmod_small(idx[e], nct, inv_nct, i, t);
+      Ent x;
+      x.off = (uint32_t)i * (uint32_t)ldp_bytes;
+      x.val = val[e];
+      out[atomicAdd(&cnt[t], 4u)] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// U consecutive steps of one quad: four rows advance together, one per lane group
+template <int NV, int U>
+__device__ __forceinline__ void quad_batch(v4f (&acc)[NV], const char* stage_lane, const char* tile_lane) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  u2 e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const u2*>(stage_lane + u * (QGROUPS * 8));
+  v4f w[U][NV];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) w[u][v] = *reinterpret_cast<const v4f*>(tile_lane + e[u].x + v * 256);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] += __uint_as_float(e[u].y) * w[u][v];
+}
+
+// panel rows t, t + nct, t + 2 nct, ... (clamped: slots past the last row are never referenced)
+template <int N, int LDP>
+__device__ __forceinline__ void load_tile_interleaved(v4f (&r)[N], const float* __restrict__ X, int t, int nct,
+                                                      int64_t panel_rows) {
+  constexpr int CPR = LDP / 4;   // 16-byte chunks per panel row
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int j = i * QTHREADS + (int)threadIdx.x;
+    const int64_t grow = min((int64_t)(j / CPR) * nct + t, panel_rows - 1);
+    r[i] = *reinterpret_cast<const v4f*>(X + grow * LDP + (j % CPR) * 4);
+  }
+}
+
+#define SAPCA_QPREFETCH(CT)                                                                         \
+  {                                                                                                 \
+    const int64_t cidx_ = (int64_t)rb * nct + (CT);                                                 \
+    const int64_t c_lo_ = chunk_off[cidx_];                                                         \
+    load_tile_interleaved<NP_TILE, LDP>(pt, X, (CT), nct, panel_rows);                              \
+    load_regs<NP_STAGE, QTHREADS>(ps, reinterpret_cast<const char*>(ent + c_lo_),                   \
+                                  max(16, (int)(chunk_off[cidx_ + 1] - c_lo_) * 8));                \
+  }
+#define SAPCA_QBOOKKEEPING(CT)                                                                      \
+  {                                                                                                 \
+    const int64_t cidx_ = (int64_t)rb * nct + (CT);                                                 \
+    cnt_next = lane < my_quads ? (int)steps[cidx_ * Q_BLOCK_QUADS + quad0 + lane] : 0;             \
+    woff_next = wave_off[cidx_ * QWAVES + wave];                                                    \
+  }
+
+template <int LDP, bool PREFETCH>
+__global__ void __launch_bounds__(QTHREADS)
+spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const int64_t* __restrict__ chunk_off,
+                 const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, const Ent* __restrict__ ent,
+                 int64_t panel_rows, const float* __restrict__ X, int nsplit, int tiles_per_split,
+                 float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec,
+                 int mode) {
+  constexpr int NV = LDP / 64;            // b128 reads per panel row per lane
+  constexpr int RG = q_rows_per_group(LDP);
+  constexpr int NP_TILE = Q_TILE_BYTES / (QTHREADS * 16), NP_STAGE = (Q_STAGE_BYTES + QTHREADS * 16 - 1) / (QTHREADS * 16);
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* tile = lds;
+  char* stage = lds + Q_TILE_BYTES;
+  const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int g = lane / QLANES, q = lane % QLANES;
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  const int nquads = (nrows + 3) / 4;
+  const int quad0 = q_first(wave, nquads), my_quads = q_first(wave + 1, nquads) - quad0;   // <= RG
+  const int my_rows = min(nrows, 4 * (quad0 + my_quads)) - 4 * quad0;
+  const char* tl = tile + q * 16;
+
+  v4f acc[RG][NV];
+#pragma unroll
+  for (int i = 0; i < RG; ++i)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[i][v] = v4f(0.f);
+
+  v4f pt[NP_TILE], ps[NP_STAGE];
+  int cnt_next = 0;
+  unsigned woff_next = 0;
+  if (ct0 < ct1) SAPCA_QBOOKKEEPING(ct0)
+  if (PREFETCH && ct0 < ct1) SAPCA_QPREFETCH(ct0)
+  for (int ct = ct0; ct < ct1; ++ct) {
+    if (!(mode & 8) || ct == ct0) {
+      __syncthreads();  // the previous tile's readers are done
+      if (!PREFETCH) SAPCA_QPREFETCH(ct)
+      store_regs<NP_TILE, QTHREADS>(pt, tile, Q_TILE_BYTES);
+      store_regs<NP_STAGE, QTHREADS>(ps, stage, Q_STAGE_BYTES);
+      __syncthreads();
+    }
+    const int cnt_v = cnt_next;
+    const unsigned woff = woff_next;
+    if (ct + 1 < ct1 && !(mode & 8)) SAPCA_QBOOKKEEPING(ct + 1)
+    if (PREFETCH && ct + 1 < ct1 && !(mode & 10)) SAPCA_QPREFETCH(ct + 1)
+    if (mode & 1) continue;
+    if (my_quads > 0) {
+      const char* sl = stage + (size_t)woff * 8 + g * 8;
+#pragma unroll
+      for (int j = 0; j < RG; ++j) {
+        int n = __builtin_amdgcn_readlane(cnt_v, j);
+        while (n >= 4) {
+          quad_batch<NV, 4>(acc[j], sl, tl);
+          sl += 4 * QGROUPS * 8;
+          n -= 4;
+        }
+        if (n >= 2) {
+          quad_batch<NV, 2>(acc[j], sl, tl);
+          sl += 2 * QGROUPS * 8;
+          n -= 2;
+        }
+        if (n) {
+          quad_batch<NV, 1>(acc[j], sl, tl);
+          sl += QGROUPS * 8;
+        }
+      }
+    }
+  }
+
+  // lane (g, q) holds columns 4q..4q+3 (and 64+4q.. for 128-wide panels) of row 4j+g of its wave
+  float* dst_base = out + (nsplit > 1 ? (int64_t)sp * out_rows_total * ldo : 0);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = v * 64 + q * 4;
+    float cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cv[i] = (cvec && nsplit == 1 && col + i < ncols) ? cvec[col + i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+      const int r = 4 * j + g;
+      if (r < my_rows) {
+        float* y = dst_base + (int64_t)(row0 + 4 * quad0 + r) * ldo + col;
+        if (col + 3 < ncols) {
+          v4f o = acc[j][v];
+          o.x -= cv[0]; o.y -= cv[1]; o.z -= cv[2]; o.w -= cv[3];
+          *reinterpret_cast<v4f*>(y) = o;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (col + i < ncols) y[i] = acc[j][v][i] - cv[i];
+        }
+      }
+    }
+  }
+}
+#undef SAPCA_QPREFETCH
+#undef SAPCA_QBOOKKEEPING
+
+template <int LDP, bool PREFETCH>
+void launch_quad(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
+                 hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_quad_kernel<LDP, PREFETCH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    attr = true;
+  }
+  hipLaunchKernelGGL((spmm_quad_kernel<LDP, PREFETCH>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
+                     op.blk_row0, op.nct, op.tc, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
+                     reinterpret_cast<const Ent*>(op.ent), op.cols, X, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
+                     ncols, cvec, mode);
+}
+
 template <int LDP, int SLOTS, bool PREFETCH>
 void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
                   hipStream_t s) {
@@ -338,14 +730,18 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
   op = TiledOp();
   if (A.rows == 0 || A.nnz == 0) return false;
-  const int tc = TILE_BYTES / (ldp * 4);
+  static const int fmt_env = getenv("SAPCA_TILED_FMT") ? atoi(getenv("SAPCA_TILED_FMT")) : 1;
+  const bool quad = fmt_env == 1;   // 1: a row per 16-lane group (default); 0: two half-waves per row
+  const int tc = (quad ? Q_TILE_BYTES : TILE_BYTES) / (ldp * 4);
   const int nct = (int)((A.cols + tc - 1) / tc);
   // row blocks of <= 512 rows.  With enough rows the block count is a multiple of the 256 CUs (every
   // CU runs the same number of workgroups); with few rows (A^T) the tile range is split instead.
   static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
   const int slots = (ldp == 64 && slots_env == 4) ? 4 : 2;
-  const int waves = waves_for(slots);
-  const int block_rows = waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
+  const int waves = quad ? QWAVES : waves_for(slots);
+  const int block_rows = quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
+                              : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
+  const int stage_cap = quad ? Q_STAGE_ENTRIES : STAGE_ENTRIES;
   int64_t nrb = (A.rows + block_rows - 1) / block_rows;
   int nsplit = 1;
   if (nrb >= 192) {
@@ -357,8 +753,15 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     const int64_t nrb_fit = 512 / nsplit;
     if (nrb_fit >= nrb && nrb_fit <= A.rows) nrb = nrb_fit;
   }
+  if (quad && (A.cols >= (1 << 24) || nct > 4096)) return false;   // float-reciprocal tile arithmetic, LDS tables of the builder
+  const float inv_nct = 1.0f / (float)nct;
   int32_t* d_seg = buf.seg.as<int32_t>((size_t)A.rows * (nct + 1));
-  build_tile_index(A, tc, nct, d_seg, s);
+  if (quad) {
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(A.rows, 4, 8192)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
+                       A.ptr, A.idx, A.rows, nct, inv_nct, d_seg);
+  } else {
+    build_tile_index(A, tc, nct, d_seg, s);
+  }
   // The entries of one (row block, tile) must fit the LDS staging.  Skewed inputs (a dense cluster
   // inside one tile) can exceed it: halve the rows per block and recount, a few times at most.
   int tiles_per_split = 0;
@@ -366,6 +769,7 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   int32_t* d_blk = nullptr;
   uint8_t* d_steps = nullptr;
   uint32_t* d_wave_off = nullptr;
+  uint32_t* d_quad_off = nullptr;
   int64_t* d_chunk = nullptr;
   for (int attempt = 0;; ++attempt) {
     tiles_per_split = (nct + nsplit - 1) / nsplit;
@@ -376,10 +780,14 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     d_blk = buf.blk.as<int32_t>((size_t)nrb + 1);
     d_steps = buf.steps.as<uint8_t>((size_t)nchunks * BLOCK_ROWS);
     d_wave_off = buf.wave_off.as<uint32_t>((size_t)nchunks * waves);
+    if (quad) d_quad_off = buf.run.as<uint32_t>((size_t)nchunks * Q_BLOCK_QUADS);
     d_chunk = buf.chunk_off.as<int64_t>((size_t)nchunks + 1);
     SAPCA_HIP(hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (slots == 2)
-      hipLaunchKernelGGL((tiled_count_kernel<16, 2>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
+    if (quad)
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
+                         reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
+    else if (slots == 2)
+      hipLaunchKernelGGL((tiled_count_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
                          d_steps, d_wave_off, d_chunk);
     else
       hipLaunchKernelGGL((tiled_count_kernel<8, 4>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
@@ -403,9 +811,9 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     total = host[1];
     if (getenv("SAPCA_DEBUG"))
       fprintf(stderr, "sapca: build_tiled rows %lld cols %lld nrb %lld nct %d split %d max_chunk %lld (cap %d) total %lld\n",
-              (long long)A.rows, (long long)A.cols, (long long)nrb, nct, nsplit, (long long)max_chunk, STAGE_ENTRIES,
+              (long long)A.rows, (long long)A.cols, (long long)nrb, nct, nsplit, (long long)max_chunk, stage_cap,
               (long long)total);
-    if (max_chunk <= STAGE_ENTRIES) break;
+    if (max_chunk <= stage_cap) break;
     if (attempt == 3 || nrb * 2 > A.rows) return false;  // does not fit: the caller stays on the row kernel
     nrb *= 2;
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
@@ -414,19 +822,22 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
   uint32_t* run_global = nullptr;
-  if (lds > 48 * 1024) {
+  if (!quad && lds > 48 * 1024) {
     run_global = buf.run.as<uint32_t>((size_t)nrb * waves * nct);
     lds = 0;
   }
-  if (slots == 2)
-    hipLaunchKernelGGL((tiled_fill_kernel<16, 2>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+  if (quad)
+    hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((A.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
+                       A.ptr, A.idx, A.val, A.rows, d_blk, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+  else if (slots == 2)
+    hipLaunchKernelGGL((tiled_fill_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   else
     hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)(nrb * 8)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   SAPCA_HIP(hipGetLastError());
   op.rows = A.rows; op.cols = A.cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
-  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots;
+  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0;
   op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
@@ -447,7 +858,11 @@ void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols,
     nc = op.ldp;
   }
   const bool pf = !(mode & 4);
-  if (op.ldp == 64 && op.slots == 4) {
+  if (op.fmt == 1) {
+    if (op.ldp == 64 && pf) launch_quad<64, true>(op, X, out, ldo, nc, cvec, mode, s);
+    else if (op.ldp == 64) launch_quad<64, false>(op, X, out, ldo, nc, cvec, mode, s);
+    else launch_quad<128, false>(op, X, out, ldo, nc, cvec, mode, s);
+  } else if (op.ldp == 64 && op.slots == 4) {
     if (pf) launch_tiled<64, 4, true>(op, X, out, ldo, nc, cvec, mode, s);
     else launch_tiled<64, 4, false>(op, X, out, ldo, nc, cvec, mode, s);
   } else if (op.ldp == 64) {

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libsapca.so"))
+# SAPCA_LIB_PATH points at another build of the same library (kernel experiments, tools/abl_build.sh)
+LIB_PATH = os.environ.get("SAPCA_LIB_PATH") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libsapca.so"))
 
 OK, ERR_ARG, ERR_MASK_LEN, ERR_NOT_FITTED, ERR_SVD, ERR_HIP, ERR_COMM, ERR_NOMEM = range(8)
 LANCZOS, RANDOM = 0, 1

@@ -1,4 +1,4 @@
-for mode in 0 1 2 3; do
-  SAPCA_TILED_MODE=$mode python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('mode $mode', 'sweep_ms', round(d['roofline']['avg_launch_ms'],3), 'spmm', round(d['config']['stage_ms']['spmm_ms'],2), 'spmmt', round(d['config']['stage_ms']['spmmt_ms'],2))"
-done
+# usage (GPU box): bash tools/abl.sh "abl0 abl1 ..." "0 8 10"   -- variants built by tools/abl_build.sh x SAPCA_TILED_MODE values
+for v in $1; do for mode in $2; do
+  SAPCA_LIB_PATH=single-algebra_amd/lib/exp/libsapca_$v.so SAPCA_TILED_MODE=$mode timeout -k 10 120 python tools/abl_run.py 2>/dev/null || exit 1
+done; done
