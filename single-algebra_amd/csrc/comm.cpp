@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -64,7 +65,9 @@ void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
   SAPCA_CHECK(nranks_ >= 1 && rank_ < nranks_, SAPCA_ERR_ARG, "comm: rank out of range");
   nranks = nranks_;
   rank = rank_;
-  if (nranks == 1) { mode = NONE; return; }
+  // a one-rank job needs no collective; SAPCA_COMM_FORCE_RCCL=1 still builds the communicator and
+  // routes every all-reduce site through RCCL (a copy), which is how a one-GPU box tests the binding
+  if (nranks == 1 && !getenv("SAPCA_COMM_FORCE_RCCL")) { mode = NONE; return; }
   RcclId u;
   std::memcpy(u.internal, id, 128);
   ncclComm_t c = nullptr;

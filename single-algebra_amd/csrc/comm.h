@@ -15,7 +15,7 @@ struct Comm {
   void* ctx = nullptr;
   double host_ms = 0;  // accumulated host-observed time inside collectives
 
-  bool active() const { return nranks > 1; }
+  bool active() const { return mode != NONE; }
   void init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]);
   void set_callback(uint32_t nranks_, uint32_t rank_, sapca_allreduce_fn f, void* c);
   // dtype: 0 = f32, 1 = f64.  In place on a device buffer, ordered on `s`.

@@ -89,7 +89,7 @@ struct TiledOp {
   const void* ent = nullptr;           // {u32 lds byte offset, f32 value}
 };
 struct TiledBuffers {
-  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run;
+  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank;
 };
 
 struct Stream {

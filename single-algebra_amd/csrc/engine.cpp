@@ -184,8 +184,10 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_used * ldp * 4.0 / tile_bytes);
         const bool dense_enough = (double)h.a_used.nnz * 64.0 >= chunks * tile_bytes;
         const bool want = h.opt.spmm_variant == 2 || dense_enough;
-        const bool ok_a = want && k::build_tiled(view(h.a_used), ldp, h.tiled_a, h.tb_a, s);
-        const bool ok_at = ok_a && k::build_tiled(view(h.at_used), ldp, h.tiled_at, h.tb_at, s);
+        const bool from_at = getenv("SAPCA_TILED_FROM_AT") != nullptr;   // debug: build A^T's format from the transposed CSR
+        const bool ok_a = want && k::build_tiled(view(h.a_used), false, ldp, h.tiled_a, h.tb_a, s);
+        const bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, ldp, h.tiled_at, h.tb_at, s)) ||
+                                    k::build_tiled(view(h.at_used), false, ldp, h.tiled_at, h.tb_at, s));
         if (h.opt.verbose)
           fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
                   ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,

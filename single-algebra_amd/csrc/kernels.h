@@ -47,7 +47,9 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
 // Builds the tile-major format of an f32 operator for panels of leading dimension ldp (64/128).
 // Returns false (op.valid == false) when the operator does not fit the LDS staging; callers then
 // stay on the row kernel.
-bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
+// transposed: the operator is S^T, built straight from S (no transposed CSR needed); false when the
+// format cannot be built (the caller stays on the row kernel)
+bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
 void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s);
 

@@ -42,11 +42,11 @@ constexpr int RW = 32;            // max rows per wave (register accumulators)
 #ifndef SAPCA_RW2
 #define SAPCA_RW2 32
 #endif
-#ifndef SAPCA_PIPE
-#define SAPCA_PIPE 0
-#endif
 #ifndef SAPCA_PADSTEPS
 #define SAPCA_PADSTEPS 1   // row segments of the two-lane-group format are padded to this many steps
+#endif
+#ifndef SAPCA_FILLEXP
+#define SAPCA_FILLEXP 0
 #endif
 #ifndef SAPCA_ABL
 #define SAPCA_ABL 0   // compile-time ablations of the sweep's inner loop (tools/abl_build.sh); 0 in the product
@@ -200,41 +200,6 @@ __device__ __forceinline__ void steps_batch(typename Lane<VPL>::V& acc, const ch
 #endif
 }
 
-// Pipelined variant for two lane groups: rows are walked in static pairs (two accumulators), the
-// pair's steps form ONE stream cut into batches of up to 4, and the entries of the next batch are
-// read while the current batch's panel gathers are in flight, so a batch costs one LDS round trip
-// instead of two.  `e` always holds the entries of the 4 steps at `sl`; the first k consumed steps
-// belong to acc0, the rest to acc1 (k is wave-uniform).
-typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void load_entries4(u2v (&e)[4], const char* p) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const u2v*>(p + u * 16);
-}
-template <int U>
-__device__ __forceinline__ void pair_batch(v2f& acc0, v2f& acc1, u2v (&e)[4], const char*& sl, const char* tl, int k) {
-  v2f w[U];
-  float a[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const v2f*>(tl + e[u].x);
-#pragma unroll
-  for (int u = 0; u < U; ++u) a[u] = __uint_as_float(e[u].y);
-  sl += U * 16;
-  load_entries4(e, sl);
-  if (k >= U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc0 += a[u] * w[u];
-  } else if (k <= 0) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc1 += a[u] * w[u];
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (u < k) acc0 += a[u] * w[u];
-      else acc1 += a[u] * w[u];
-    }
-  }
-}
-
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int np_tile(int threads) { return TILE_BYTES / (threads * 16); }
 constexpr int np_stage(int threads) { return (STAGE_BYTES + threads * 16 - 1) / (threads * 16); }
@@ -325,23 +290,6 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
     if (mode & 1) continue;
     if (my_rows > 0) {
       const char* sl = stage + (size_t)woff * 8 + half * 8;
-      if constexpr (SLOTS == 2 && LDP == 64 && SAPCA_PIPE) {
-        u2v e[4];
-        load_entries4(e, sl);
-#pragma unroll
-        for (int rr = 0; rr < RWK; rr += 2) {
-          int k = __builtin_amdgcn_readlane(cnt_v, rr);
-          int n = k + __builtin_amdgcn_readlane(cnt_v, rr + 1);
-          while (n >= 4) {
-            pair_batch<4>(acc[rr], acc[rr + 1], e, sl, tl, k);
-            k -= 4;
-            n -= 4;
-          }
-          if (n == 3) pair_batch<3>(acc[rr], acc[rr + 1], e, sl, tl, k);
-          else if (n == 2) pair_batch<2>(acc[rr], acc[rr + 1], e, sl, tl, k);
-          else if (n == 1) pair_batch<1>(acc[rr], acc[rr + 1], e, sl, tl, k);
-        }
-      } else
 #pragma unroll
       for (int rr = 0; rr < RWK; ++rr) {
         int n = __builtin_amdgcn_readlane(cnt_v, rr);
@@ -542,9 +490,175 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
       Ent x;
       x.off = (uint32_t)i * (uint32_t)ldp_bytes;
       x.val = val[e];
+#if SAPCA_FILLEXP == 1   // experiment: no scattered store
+      const uint32_t pos = atomicAdd(&cnt[t], 4u);
+      if (pos == 0xffffffffu) out[pos] = x;
+#elif SAPCA_FILLEXP == 2   // experiment: linear store
+      const uint32_t pos = atomicAdd(&cnt[t], 4u);
+      ent[e + (pos == 0xffffffffu)] = x;
+#else
       out[atomicAdd(&cnt[t], 4u)] = x;
+#endif
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- the same format for A^T, built straight from A (no transposed CSR, no global sort) ----------
+// Operator T = S^T for a source S (m x n CSR): T's rows are S's columns, T's interleaved tiles run
+// over S's rows.  The chunk (block b of T rows, tile t) receives, from every source row r = t + i*nct,
+// the contiguous run of its entries whose column lies in block b (found through segb), so one
+// workgroup per chunk reads ~|block| * density entries per source row and owns the chunk's whole
+// output region.  The rank of an entry inside its T row's segment (= the number of earlier source
+// rows of this tile holding the same column) comes from per-column bit masks over the tile's rows,
+// so the result is byte-identical to what the builder above makes from a transposed CSR.
+
+// segb[r][b] = number of entries of row r with column < bounds[b]   (b = 0..nb)
+__global__ void bound_index_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
+                                   const int32_t* __restrict__ bounds, int nb, int32_t* __restrict__ segb) {
+  const int64_t total = rows * (int64_t)(nb + 1);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t r = i / (nb + 1);
+    const int b = (int)(i - r * (nb + 1));
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    const int bound = bounds[b];
+    int64_t lo = e0, hi = e1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (idx[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    segb[i] = (int32_t)(lo - e0);
+  }
+}
+
+constexpr int TQ_THREADS = 1024, TQ_GROUPS = TQ_THREADS / 16;
+constexpr int TQ_NI = 5;   // source rows per 16-lane group: a tile holds at most 320 = 5 * 64 rows
+
+// the run of source row i of this tile inside the chunk's column block: [e0, e1)
+__device__ __forceinline__ void tquad_runs(int64_t (&e0)[TQ_NI], int64_t (&e1)[TQ_NI], const int64_t* __restrict__ ptr,
+                                           const int32_t* __restrict__ segb, int nb, int b, int t, int nct, int nr) {
+  const int grp = threadIdx.x / 16;
+#pragma unroll
+  for (int j = 0; j < TQ_NI; ++j) {
+    const int i = grp + j * TQ_GROUPS;
+    e0[j] = e1[j] = 0;
+    if (i < nr) {
+      const int64_t r = (int64_t)t + (int64_t)i * nct;
+      const int64_t base = ptr[r];
+      const int32_t* sb = segb + r * (nb + 1) + b;
+      e0[j] = base + sb[0];
+      e1[j] = base + sb[1];
+    }
+  }
+}
+
+// Per chunk: bit i of mask[column] <- source row i stores the column; the number of set bits below
+// bit i is the entry's rank in its T row's segment (written to rank[], aligned with the source
+// entries); the longest of a quad's four columns gives its steps.
+__global__ void __launch_bounds__(TQ_THREADS)
+tquad_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const int32_t* __restrict__ segb,
+                   int64_t src_rows, const int32_t* __restrict__ blk_row0, int nb, int nct, int maskw,
+                   uint16_t* __restrict__ rank, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off,
+                   uint32_t* __restrict__ wave_off, int64_t* __restrict__ chunk_size) {
+  extern __shared__ uint32_t tq_lds[];
+  uint32_t* mask = tq_lds;                                   // [BLOCK_ROWS][maskw]
+  uint32_t* pre = tq_lds + (size_t)BLOCK_ROWS * maskw;       // [BLOCK_ROWS][maskw]: set bits in the words before
+  __shared__ uint32_t wsum[BLOCK_ROWS / WAVE];
+  __shared__ uint32_t qex[Q_BLOCK_QUADS];
+  // launch order: all column blocks of one tile are neighbours, so the source rows they share
+  // (and the segb lines) are fetched from HBM once and then hit in L2 / Infinity Cache
+  const int t = blockIdx.x / nb, b = blockIdx.x % nb;
+  const int64_t chunk = (int64_t)b * nct + t;
+  const int c0 = blk_row0[b], nrows = blk_row0[b + 1] - c0;
+  const int nquads = (nrows + 3) / 4;
+  const int nr = (int)((src_rows - t + nct - 1) / nct);
+  const int grp = threadIdx.x / 16, gl = threadIdx.x & 15;
+  int64_t e0[TQ_NI], e1[TQ_NI];
+  tquad_runs(e0, e1, ptr, segb, nb, b, t, nct, nr);
+  for (int i = threadIdx.x; i < BLOCK_ROWS * maskw; i += TQ_THREADS) mask[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TQ_NI; ++j) {
+    const int i = grp + j * TQ_GROUPS;
+    for (int64_t e = e0[j] + gl; e < e1[j]; e += 16) atomicOr(&mask[(idx[e] - c0) * maskw + (i >> 5)], 1u << (i & 31));
+  }
+  __syncthreads();
+  const int lr = threadIdx.x;
+  int len = 0;
+  if (lr < nrows) {
+    for (int d = 0; d < maskw; ++d) {
+      pre[lr * maskw + d] = (uint32_t)len;
+      len += __popc(mask[lr * maskw + d]);
+    }
+  }
+  // steps of every quad, exclusive scan of the padded quad sizes (wave scans + 8 wave totals)
+  uint32_t padded = 0, incl = 0;
+  const int lane = lr & (WAVE - 1), wv = lr / WAVE;
+  if (lr < BLOCK_ROWS) {
+    int qmax = max(len, __shfl_xor(len, 1));
+    qmax = max(qmax, __shfl_xor(qmax, 2));
+    padded = (lr & 3) == 0 ? (uint32_t)qmax * 4u : 0u;
+    if ((lr & 3) == 0) steps[chunk * Q_BLOCK_QUADS + lr / 4] = (uint16_t)qmax;
+    incl = padded;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const uint32_t y = __shfl_up(incl, off);
+      if (lane >= off) incl += y;
+    }
+    if (lane == WAVE - 1) wsum[wv] = incl;
+  }
+  __syncthreads();
+  if (lr < BLOCK_ROWS) {
+    uint32_t before = 0;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    incl += before;
+    if ((lr & 3) == 0) {
+      quad_off[chunk * Q_BLOCK_QUADS + lr / 4] = incl - padded;
+      qex[lr / 4] = incl - padded;
+    }
+    if (lr == BLOCK_ROWS - 1) chunk_size[chunk] = incl;
+  }
+  __syncthreads();
+  if (lr < QWAVES) wave_off[chunk * QWAVES + lr] = qex[q_first(lr, nquads)];
+  // ranks of this chunk's entries (idx is re-read: cache hits)
+#pragma unroll
+  for (int j = 0; j < TQ_NI; ++j) {
+    const int i = grp + j * TQ_GROUPS;
+    for (int64_t e = e0[j] + gl; e < e1[j]; e += 16) {
+      const int w = (idx[e] - c0) * maskw + (i >> 5);
+      rank[e] = (uint16_t)(pre[w] + __popc(mask[w] & ((1u << (i & 31)) - 1u)));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(TQ_THREADS)
+tquad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+                  const uint16_t* __restrict__ rank, const int32_t* __restrict__ segb, int64_t src_rows,
+                  const int32_t* __restrict__ blk_row0, int nb, int nct, int ldp_bytes,
+                  const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off, Ent* __restrict__ ent) {
+  __shared__ uint32_t qoff[Q_BLOCK_QUADS];
+  const int t = blockIdx.x / nb, b = blockIdx.x % nb;
+  const int64_t chunk = (int64_t)b * nct + t;
+  const int c0 = blk_row0[b];
+  const int nr = (int)((src_rows - t + nct - 1) / nct);
+  const int grp = threadIdx.x / 16, gl = threadIdx.x & 15;
+  int64_t e0[TQ_NI], e1[TQ_NI];
+  tquad_runs(e0, e1, ptr, segb, nb, b, t, nct, nr);
+  if (threadIdx.x < Q_BLOCK_QUADS) qoff[threadIdx.x] = quad_off[chunk * Q_BLOCK_QUADS + threadIdx.x];
+  __syncthreads();
+  Ent* __restrict__ out = ent + chunk_off[chunk];
+#pragma unroll
+  for (int j = 0; j < TQ_NI; ++j) {
+    const int i = grp + j * TQ_GROUPS;
+    for (int64_t e = e0[j] + gl; e < e1[j]; e += 16) {
+      const int lr = idx[e] - c0;
+      Ent x;
+      x.off = (uint32_t)i * (uint32_t)ldp_bytes;
+      x.val = val[e];
+      out[qoff[lr >> 2] + (uint32_t)rank[e] * 4u + (uint32_t)(lr & 3)] = x;
+    }
   }
 }
 
@@ -553,17 +667,45 @@ template <int NV, int U>
 __device__ __forceinline__ void quad_batch(v4f (&acc)[NV], const char* stage_lane, const char* tile_lane) {
   typedef unsigned int u2 __attribute__((ext_vector_type(2)));
   u2 e[U];
+#if SAPCA_ABL & 2   // ablation: no entry reads
+  {
+    u2 f;
+    f.x = (unsigned)(size_t)stage_lane & 0xff00u;
+    f.y = 0x3f800000u;
+    asm volatile("" : "+v"(f));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      e[u] = f;
+      e[u].x += u * 512;
+    }
+  }
+#else
 #pragma unroll
   for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const u2*>(stage_lane + u * (QGROUPS * 8));
+#endif
   v4f w[U][NV];
+#if SAPCA_ABL & 1   // ablation: no panel gathers
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) w[u][v] = v4f(__uint_as_float(e[u].x));
+#else
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int v = 0; v < NV; ++v) w[u][v] = *reinterpret_cast<const v4f*>(tile_lane + e[u].x + v * 256);
+#endif
+#if SAPCA_ABL & 4   // ablation: no FMAs
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(w[u][v]), "v"(e[u].y));
+#else
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] += __uint_as_float(e[u].y) * w[u][v];
+#endif
 }
 
 // panel rows t, t + nct, t + 2 nct, ... (clamped: slots past the last row are never referenced)
@@ -726,14 +868,18 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 }  // namespace
 
 // ---------------------------------------------------------------------------------- host side
-bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s) {
+bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
   op = TiledOp();
-  if (A.rows == 0 || A.nnz == 0) return false;
+  if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
+  // the operator is S, or S^T built straight from S (quad format only)
+  const int64_t op_rows = transposed ? S.cols : S.rows, op_cols = transposed ? S.rows : S.cols;
   static const int fmt_env = getenv("SAPCA_TILED_FMT") ? atoi(getenv("SAPCA_TILED_FMT")) : 1;
   const bool quad = fmt_env == 1;   // 1: a row per 16-lane group (default); 0: two half-waves per row
   const int tc = (quad ? Q_TILE_BYTES : TILE_BYTES) / (ldp * 4);
-  const int nct = (int)((A.cols + tc - 1) / tc);
+  if (transposed && (!quad || (tc + 63) / 64 > TQ_NI)) return false;
+  const int nct = (int)((op_cols + tc - 1) / tc);
+  const int maskw = (tc + 31) / 32;
   // row blocks of <= 512 rows.  With enough rows the block count is a multiple of the 256 CUs (every
   // CU runs the same number of workgroups); with few rows (A^T) the tile range is split instead.
   static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
@@ -742,7 +888,7 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   const int block_rows = quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
                               : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
   const int stage_cap = quad ? Q_STAGE_ENTRIES : STAGE_ENTRIES;
-  int64_t nrb = (A.rows + block_rows - 1) / block_rows;
+  int64_t nrb = (op_rows + block_rows - 1) / block_rows;
   int nsplit = 1;
   if (nrb >= 192) {
     nrb = round_up(nrb, 256);
@@ -751,16 +897,19 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     // multiple of the 256 CUs -- one workgroup per CU per round, no half-empty last round
     nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, 512 / nrb));
     const int64_t nrb_fit = 512 / nsplit;
-    if (nrb_fit >= nrb && nrb_fit <= A.rows) nrb = nrb_fit;
+    if (nrb_fit >= nrb && nrb_fit <= op_rows) nrb = nrb_fit;
   }
-  if (quad && (A.cols >= (1 << 24) || nct > 4096)) return false;   // float-reciprocal tile arithmetic, LDS tables of the builder
+  if (quad && !transposed && (op_cols >= (1 << 24) || nct > 4096)) return false;   // float-reciprocal tile arithmetic, LDS tables of the builder
   const float inv_nct = 1.0f / (float)nct;
-  int32_t* d_seg = buf.seg.as<int32_t>((size_t)A.rows * (nct + 1));
-  if (quad) {
-    hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(A.rows, 4, 8192)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
-                       A.ptr, A.idx, A.rows, nct, inv_nct, d_seg);
-  } else {
-    build_tile_index(A, tc, nct, d_seg, s);
+  int32_t* d_seg = nullptr;
+  if (!transposed) {
+    d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nct + 1));
+    if (quad) {
+      hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(S.rows, 4, 8192)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
+                         S.ptr, S.idx, S.rows, nct, inv_nct, d_seg);
+    } else {
+      build_tile_index(S, tc, nct, d_seg, s);
+    }
   }
   // The entries of one (row block, tile) must fit the LDS staging.  Skewed inputs (a dense cluster
   // inside one tile) can exceed it: halve the rows per block and recount, a few times at most.
@@ -770,12 +919,13 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
   uint8_t* d_steps = nullptr;
   uint32_t* d_wave_off = nullptr;
   uint32_t* d_quad_off = nullptr;
+  uint16_t* d_rank = nullptr;
   int64_t* d_chunk = nullptr;
   for (int attempt = 0;; ++attempt) {
     tiles_per_split = (nct + nsplit - 1) / nsplit;
     nsplit = (nct + tiles_per_split - 1) / tiles_per_split;
     std::vector<int32_t> blk((size_t)nrb + 1);
-    for (int64_t b = 0; b <= nrb; ++b) blk[(size_t)b] = (int32_t)(A.rows * b / nrb);
+    for (int64_t b = 0; b <= nrb; ++b) blk[(size_t)b] = (int32_t)(op_rows * b / nrb);
     nchunks = nrb * nct;
     d_blk = buf.blk.as<int32_t>((size_t)nrb + 1);
     d_steps = buf.steps.as<uint8_t>((size_t)nchunks * BLOCK_ROWS);
@@ -783,7 +933,15 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     if (quad) d_quad_off = buf.run.as<uint32_t>((size_t)nchunks * Q_BLOCK_QUADS);
     d_chunk = buf.chunk_off.as<int64_t>((size_t)nchunks + 1);
     SAPCA_HIP(hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (quad)
+    if (transposed) {
+      d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nrb + 1));
+      hipLaunchKernelGGL(bound_index_kernel, dim3(grid_for(S.rows * (nrb + 1), 256, 16384)), dim3(256), 0, s, S.ptr, S.idx,
+                         S.rows, d_blk, (int)nrb, d_seg);
+      d_rank = buf.rank.as<uint16_t>((size_t)S.nnz);
+      hipLaunchKernelGGL(tquad_count_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS),
+                         (size_t)2 * BLOCK_ROWS * maskw * sizeof(uint32_t), s, S.ptr, S.idx, d_seg, S.rows, d_blk, (int)nrb, nct,
+                         maskw, d_rank, reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
+    } else if (quad)
       hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     else if (slots == 2)
@@ -810,11 +968,11 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     max_chunk = host[0];
     total = host[1];
     if (getenv("SAPCA_DEBUG"))
-      fprintf(stderr, "sapca: build_tiled rows %lld cols %lld nrb %lld nct %d split %d max_chunk %lld (cap %d) total %lld\n",
-              (long long)A.rows, (long long)A.cols, (long long)nrb, nct, nsplit, (long long)max_chunk, stage_cap,
-              (long long)total);
+      fprintf(stderr, "sapca: build_tiled%s rows %lld cols %lld nrb %lld nct %d split %d max_chunk %lld (cap %d) total %lld\n",
+              transposed ? " (transposed source)" : "", (long long)op_rows, (long long)op_cols, (long long)nrb, nct, nsplit,
+              (long long)max_chunk, stage_cap, (long long)total);
     if (max_chunk <= stage_cap) break;
-    if (attempt == 3 || nrb * 2 > A.rows) return false;  // does not fit: the caller stays on the row kernel
+    if (attempt == 3 || nrb * 2 > op_rows) return false;  // does not fit: the caller stays on the row kernel
     nrb *= 2;
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
   }
@@ -826,17 +984,20 @@ bool build_tiled(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& bu
     run_global = buf.run.as<uint32_t>((size_t)nrb * waves * nct);
     lds = 0;
   }
-  if (quad)
-    hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((A.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
-                       A.ptr, A.idx, A.val, A.rows, d_blk, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+  if (transposed)
+    hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
+                       S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+  else if (quad)
+    hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
+                       S.ptr, S.idx, S.val, S.rows, d_blk, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (slots == 2)
-    hipLaunchKernelGGL((tiled_fill_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+    hipLaunchKernelGGL((tiled_fill_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, S.ptr, S.idx, S.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   else
-    hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)(nrb * 8)), dim3(WAVE), lds, s, A.ptr, A.idx, A.val, d_seg,
+    hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)(nrb * 8)), dim3(WAVE), lds, s, S.ptr, S.idx, S.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   SAPCA_HIP(hipGetLastError());
-  op.rows = A.rows; op.cols = A.cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
+  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0;
   op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;

@@ -63,3 +63,45 @@ def test_two_rank_row_sharded_fit(tmp_path, method):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), method), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.gpu
+def test_rccl_binding_with_a_one_rank_communicator(monkeypatch):
+    """One GPU cannot host two RCCL ranks, but a one-rank communicator still exercises the library's own
+    RCCL binding (dlopen, ncclCommInitRank by-value id, ncclAllReduce on the library stream) at every
+    all-reduce site of a fit; the result must equal the fit without a communicator."""
+    import numpy as np
+    import torch
+    import sapca
+    from sapca import synth
+    from sapca import _lib as L
+    import ctypes as C
+    m, n, k, p, q = 5000, 800, 10, 6, 2
+    ptr, idx, val = synth.gapped_csr(m, n, 0.05, k, seed=9, dtype=torch.float32, device="cuda")
+    x = sapca.DeviceCsr(ptr, idx, val, (m, n))
+    om = synth.gaussian_panel(n, k + p, 4).numpy()
+
+    def build():
+        return (sapca.SparsePCABuilder.new().n_components(k).random_seed(1)
+                .svd_method(sapca.SVDMethod.Random(p, q, sapca.PowerIterationNormalizer.QR)).build().set_omega(om))
+
+    ref = build()
+    t_ref = ref.fit_transform(x).cpu().numpy()
+    monkeypatch.setenv("SAPCA_COMM_FORCE_RCCL", "1")
+    buf = (C.c_uint8 * 128)()
+    assert L.load().sapca_comm_unique_id(buf) == L.OK
+    est = build()
+    est.comm_init_rank(1, 0, bytes(buf))
+    t = est.fit_transform(x).cpu().numpy()
+    np.testing.assert_array_equal(est.singular_values_(np.float64), ref.singular_values_(np.float64))
+    np.testing.assert_array_equal(t, t_ref)
+    # Lanczos path: the per-step vector all-reduce
+    lz = (sapca.SparsePCABuilder.new().n_components(k).svd_method(sapca.SVDMethod.Lanczos()).build())
+    lz_ref = (sapca.SparsePCABuilder.new().n_components(k).svd_method(sapca.SVDMethod.Lanczos()).build())
+    buf2 = (C.c_uint8 * 128)()                 # a communicator id is one-shot
+    assert L.load().sapca_comm_unique_id(buf2) == L.OK
+    lz.comm_init_rank(1, 0, bytes(buf2))
+    lz.fit(x)
+    monkeypatch.delenv("SAPCA_COMM_FORCE_RCCL")
+    lz_ref.fit(x)
+    np.testing.assert_allclose(lz.singular_values_(np.float64), lz_ref.singular_values_(np.float64), rtol=1e-12)
