@@ -86,13 +86,35 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
   h.prep_key.valid = false;
 
+  // LDS-staged sweep (f32, randomized): decided here because it fixes the order in which the transposed
+  // rows are produced.  It refills an 80 KiB panel tile per (row block, column tile) chunk and only beats
+  // the row-gather kernel when a chunk carries enough entries to amortise that fill (measured: 64 tile
+  // bytes per entry or less -> clearly faster; 164 -> no gain, 4x the prepare time).
+  int tiled_ldp = 0;
+  if constexpr (sizeof(T) == 4) {
+    if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
+      const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
+      const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
+      if (l >= 1 && l <= 128 && n_kept > 0) {
+        const int ldp = l <= 64 ? 64 : 128;
+        const double tile_bytes = 80.0 * 1024.0, block_rows = ldp == 64 ? 512.0 : 256.0;
+        const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_kept * ldp * 4.0 / tile_bytes);
+        const bool dense_enough = (double)nnz * ((double)n_kept / (double)n) * 64.0 >= chunks * tile_bytes;
+        if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
+      }
+    }
+  }
+  const bool from_at = getenv("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
+  const bool at_tile_major = tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
+
   CsrView<T> At;
   {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
     int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* at_val = h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s);
+    // rows of A^T grouped by the interleaved tile of the A row they came from: its format fill streams
+    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp) : 0);
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
   }
 
@@ -167,33 +189,20 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     h.at_used = {n, m, nnz, At.ptr, At.idx, At.val};
   }
 
-  // tile-major companions for the LDS-staged sweep (f32; panel width from the requested rank)
+  // tile-major companions for the LDS-staged sweep
   h.tiled_a = TiledOp();
   h.tiled_at = TiledOp();
   if constexpr (sizeof(T) == 4) {
-    if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && n_used > 0) {
+    if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
-      const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples),
-                                          std::min<int64_t>((int64_t)h.m_global, n_used));
-      if (l >= 1 && l <= 128) {
-        const int ldp = l <= 64 ? 64 : 128;
-        // The staged sweep refills an 80 KiB panel tile per (512-row block, column tile) chunk; it only
-        // beats the row-gather kernel when a chunk carries enough entries to amortise that fill
-        // (measured: 64 tile bytes per entry or less -> clearly faster; 164 -> no gain, 4x the prepare time).
-        const double tile_bytes = 80.0 * 1024.0, block_rows = ldp == 64 ? 512.0 : 256.0;
-        const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_used * ldp * 4.0 / tile_bytes);
-        const bool dense_enough = (double)h.a_used.nnz * 64.0 >= chunks * tile_bytes;
-        const bool want = h.opt.spmm_variant == 2 || dense_enough;
-        const bool from_at = getenv("SAPCA_TILED_FROM_AT") != nullptr;   // debug: build A^T's format from the transposed CSR
-        const bool ok_a = want && k::build_tiled(view(h.a_used), false, ldp, h.tiled_a, h.tb_a, s);
-        const bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, ldp, h.tiled_at, h.tb_at, s)) ||
-                                    k::build_tiled(view(h.at_used), false, ldp, h.tiled_at, h.tb_at, s));
-        if (h.opt.verbose)
-          fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
-                  ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
-                  ok_at ? "ok" : "no", h.tiled_at.nrb, h.tiled_at.nct, h.tiled_at.nsplit, (long long)h.tiled_at.total_entries);
-        if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }
-      }
+      const bool ok_a = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
+      const bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
+                                  k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major));
+      if (h.opt.verbose)
+        fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
+                ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
+                ok_at ? "ok" : "no", h.tiled_at.nrb, h.tiled_at.nct, h.tiled_at.nsplit, (long long)h.tiled_at.total_entries);
+      if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }
     }
   }
 

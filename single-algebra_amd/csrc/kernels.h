@@ -12,7 +12,8 @@ void narrow_indices(const uint64_t* ptr64, const uint64_t* idx64, int64_t m, int
                     int64_t* ptr, int32_t* idx, int* flag, hipStream_t s);
 // CSR(A) -> CSR(A^T), entries of each A^T row in ascending A-row order (stable, deterministic).
 template <typename T>
-void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s);
+void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s,
+                   int tile_major_nct = 0);   // f32, > 1: entries of a transposed row ordered by (row mod nct, row / nct)
 // Row sums of a CSR (applied to A^T: the reference's sum_col / sum_col_squared), f64 accumulation.
 template <typename T>
 void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s);
@@ -49,7 +50,11 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
 // stay on the row kernel.
 // transposed: the operator is S^T, built straight from S (no transposed CSR needed); false when the
 // format cannot be built (the caller stays on the row kernel)
-bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
+// rows_tile_major: S's rows were produced by transpose_csr(..., tile_major_nct = tiled_tile_count(S.cols, ldp))
+bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
+                 bool rows_tile_major = false);
+// number of interleaved column tiles the format uses for an operator with `cols` columns
+int tiled_tile_count(int64_t cols, int ldp);
 void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s);
 

@@ -89,6 +89,37 @@ __global__ void pack_rows_kernel(const int64_t* __restrict__ ptr, const float* _
   }
 }
 
+// Tile-major order of the source rows: row r of tile t = r mod nct, position i = r / nct, has rank
+// rho(r) = (rows in tiles < t) + i.  Feeding the stable sort in that order makes every transposed row
+// come out grouped by tile (and by position inside the tile), which turns the A^T format fill into a
+// streaming copy.
+__device__ __forceinline__ int64_t tile_major_rank(int64_t r, int64_t rows, int nct) {
+  const int64_t base = rows / nct, rem = rows % nct;
+  const int64_t t = r % nct, i = r / nct;
+  return t * base + (t < rem ? t : rem) + i;
+}
+__global__ void permuted_len_kernel(const int64_t* __restrict__ ptr, int64_t rows, int nct, int64_t* __restrict__ lenp) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) lenp[tile_major_rank(r, rows, nct)] = ptr[r + 1] - ptr[r];
+  if (r == 0) lenp[rows] = 0;
+}
+__global__ void pack_rows_permuted_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                          const float* __restrict__ val, int64_t rows, int nct,
+                                          const int64_t* __restrict__ pptr, uint32_t* __restrict__ keys,
+                                          uint64_t* __restrict__ packed) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    const int64_t d0 = pptr[tile_major_rank(r, rows, nct)] - e0;
+    for (int64_t e = e0 + lane; e < e1; e += WAVE) {
+      keys[d0 + e] = (uint32_t)idx[e];
+      packed[d0 + e] = ((uint64_t)(uint32_t)r << 32) | (uint64_t)__float_as_uint(val[e]);
+    }
+  }
+}
+
 __global__ void unpack_rows_kernel(const uint64_t* __restrict__ packed, int64_t count, int32_t* __restrict__ t_idx,
                                    float* __restrict__ t_val) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,7 +307,8 @@ void narrow_indices(const uint64_t* ptr64, const uint64_t* idx64, int64_t m, int
 }
 
 template <typename T>
-void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s) {
+void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s,
+                   int tile_major_nct) {
   const int64_t nnz = A.nnz;
   SAPCA_CHECK(nnz < (int64_t)0xFFFFFFFFll, SAPCA_ERR_ARG, "more than 2^32-1 stored entries per shard is not supported");
   if (nnz == 0) {
@@ -291,15 +323,32 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
     SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                         (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
     const size_t a4 = (size_t)round_up(nnz * 4, 256), a8 = (size_t)round_up(nnz * 8, 256);
-    char* base = static_cast<char*>(scratch.ensure(a4 + 2 * a8 + sort_bytes + 256));
+    const bool permuted = tile_major_nct > 1;
+    const size_t extra = permuted ? a4 + (size_t)round_up((A.rows + 1) * 8, 256) : 0;   // keys in sort order, permuted row offsets
+    size_t scan_bytes = 0;
+    if (permuted)
+      SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
+                                        (size_t)A.rows + 1, rocprim::plus<int64_t>(), s));
+    char* base = static_cast<char*>(scratch.ensure(a4 + 2 * a8 + extra + std::max(sort_bytes, scan_bytes) + 256));
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(base);
     uint64_t* packed = reinterpret_cast<uint64_t*>(base + a4);
     uint64_t* packed_out = reinterpret_cast<uint64_t*>(base + a4 + a8);
-    void* tmp = base + a4 + 2 * a8;
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr,
-                       reinterpret_cast<const float*>(A.val), A.rows, packed);
-    SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, reinterpret_cast<const uint32_t*>(A.idx), keys_out, packed,
-                                        packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+    uint32_t* keys_in = reinterpret_cast<uint32_t*>(base + a4 + 2 * a8);
+    int64_t* pptr = reinterpret_cast<int64_t*>(base + a4 + 2 * a8 + a4);
+    void* tmp = base + a4 + 2 * a8 + extra;
+    if (permuted) {
+      hipLaunchKernelGGL(permuted_len_kernel, dim3(grid_for(A.rows, 256, 1 << 30)), dim3(256), 0, s, A.ptr, A.rows,
+                         tile_major_nct, pptr);
+      SAPCA_HIP(rocprim::exclusive_scan(tmp, scan_bytes, pptr, pptr, (int64_t)0, (size_t)A.rows + 1,
+                                        rocprim::plus<int64_t>(), s));
+      hipLaunchKernelGGL(pack_rows_permuted_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,
+                         reinterpret_cast<const float*>(A.val), A.rows, tile_major_nct, pptr, keys_in, packed);
+    } else {
+      hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr,
+                         reinterpret_cast<const float*>(A.val), A.rows, packed);
+    }
+    SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, permuted ? keys_in : reinterpret_cast<const uint32_t*>(A.idx),
+                                        keys_out, packed, packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
     hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out, nnz,
                        A.cols, t_ptr);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, packed_out, nnz, t_idx,
@@ -394,7 +443,7 @@ void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* 
 }
 
 #define INSTANTIATE(T)                                                                                              \
-  template void transpose_csr<T>(const CsrView<T>&, int64_t*, int32_t*, T*, DevBuf&, hipStream_t);                  \
+  template void transpose_csr<T>(const CsrView<T>&, int64_t*, int32_t*, T*, DevBuf&, hipStream_t, int);             \
   template void row_sums<T>(const CsrView<T>&, double*, double*, hipStream_t);                                      \
   template void compact_columns<T>(const CsrView<T>&, const int32_t*, int64_t*, int32_t*, T*, int64_t*, DevBuf&,    \
                                    hipStream_t);                                                                    \

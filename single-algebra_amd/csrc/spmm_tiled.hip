@@ -45,9 +45,6 @@ constexpr int RW = 32;            // max rows per wave (register accumulators)
 #ifndef SAPCA_PADSTEPS
 #define SAPCA_PADSTEPS 1   // row segments of the two-lane-group format are padded to this many steps
 #endif
-#ifndef SAPCA_FILLEXP
-#define SAPCA_FILLEXP 0
-#endif
 #ifndef SAPCA_ABL
 #define SAPCA_ABL 0   // compile-time ablations of the sweep's inner loop (tools/abl_build.sh); 0 in the product
 #endif
@@ -482,25 +479,209 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
   Ent* __restrict__ out = ent + block_base;
   // batches of 64 entries in column order; within a batch the LDS atomic hands out the ranks of
   // equal tiles (a fixed function of the input: the format is reproducible run to run)
-  for (int64_t eb = e0; eb < e1; eb += WAVE) {
-    const int64_t e = eb + lane;
-    if (e < e1) {
-      int i, t;
-      divmod_small(idx[e], nct, inv_nct, i, t);
-      Ent x;
-      x.off = (uint32_t)i * (uint32_t)ldp_bytes;
-      x.val = val[e];
-#if SAPCA_FILLEXP == 1   // experiment: no scattered store
-      const uint32_t pos = atomicAdd(&cnt[t], 4u);
-      if (pos == 0xffffffffu) out[pos] = x;
-#elif SAPCA_FILLEXP == 2   // experiment: linear store
-      const uint32_t pos = atomicAdd(&cnt[t], 4u);
-      ent[e + (pos == 0xffffffffu)] = x;
-#else
-      out[atomicAdd(&cnt[t], 4u)] = x;
-#endif
+  for (int64_t eb = e0; eb < e1; eb += 8 * WAVE) {   // 8 batches loaded ahead: one round trip per 512 entries
+    int c[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t e = eb + u * WAVE + lane;
+      c[u] = e < e1 ? idx[e] : -1;
+      v[u] = e < e1 ? val[e] : 0.f;
     }
-    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (c[u] >= 0) {
+        int i, t;
+        divmod_small(c[u], nct, inv_nct, i, t);
+        Ent x;
+        x.off = (uint32_t)i * (uint32_t)ldp_bytes;
+        x.val = v[u];
+        out[atomicAdd(&cnt[t], 4u)] = x;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// The same fill with the quad assembled in LDS first: a workgroup owns one quad (a wave per row),
+// scatters the entries into an LDS image of the quad's segments (padding pre-zeroed) and then writes
+// every tile's segment out as one contiguous run -- the direct version above issues one isolated
+// 8-byte store per entry, which is what it spends its time on.  Quads larger than the LDS image
+// (very long rows) take the direct route and zero their padding themselves, so the entry buffer
+// needs no memset on this path.
+constexpr int QF_CAP = 6144;   // entries of one quad staged in LDS (48 KiB)
+__global__ void __launch_bounds__(256)
+quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+                        const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
+                        int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
+                        Ent* __restrict__ ent) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
+  Ent* stage = reinterpret_cast<Ent*>(qf_lds);     // [QF_CAP]
+  uint32_t* lofs = qf_lds + 2 * QF_CAP;            // [nct + 1] start of every tile's segment in the image
+  uint32_t* cnt_all = lofs + nct + 1;              // [4][nct] entries of row g seen so far in tile t
+  const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  if (4 * qd >= nrows) return;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int qrows = min(4, nrows - 4 * qd);
+  const int64_t r0 = (int64_t)row0 + 4 * qd;
+  const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
+  const uint32_t* __restrict__ qoff = quad_off + ((int64_t)rb * Q_BLOCK_QUADS + qd) * nct;
+  // segment sizes (4 x the longest of the quad's rows in the tile), then their exclusive scan
+  for (int t = threadIdx.x; t < nct; t += 256) {
+    int mx = 0;
+    for (int g = 0; g < qrows; ++g) {
+      const int32_t* sg = seg + (r0 + g) * (nct + 1);
+      mx = max(mx, sg[t + 1] - sg[t]);
+    }
+    lofs[t + 1] = (uint32_t)mx * 4u;
+    for (int g = 0; g < 4; ++g) cnt_all[g * nct + t] = 0;
+  }
+  if (threadIdx.x == 0) lofs[0] = 0;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < nct; t0 += WAVE) {
+      const int t = t0 + lane;
+      const uint32_t v = t < nct ? lofs[t + 1] : 0u;
+      uint32_t x = v;
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+      }
+      if (t < nct) lofs[t + 1] = carry + x;
+      carry += __shfl(x, WAVE - 1);
+    }
+  }
+  __syncthreads();
+  const uint32_t total = lofs[nct];
+  const bool staged = total <= (uint32_t)QF_CAP;
+  if (staged) {
+    uint64_t* z = reinterpret_cast<uint64_t*>(stage);
+    for (uint32_t i = threadIdx.x; i < total; i += 256) z[i] = 0;
+  } else {
+    // direct route: zero the padding slots of this wave's row in global memory
+    if (wave < qrows) {
+      const int32_t* sg = seg + (r0 + wave) * (nct + 1);
+      for (int t = lane; t < nct; t += WAVE) {
+        const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
+        Ent* dst = ent + coff[t] + qoff[t];
+        for (uint32_t k = (uint32_t)(sg[t + 1] - sg[t]); k < steps; ++k) dst[k * 4u + wave] = Ent{0u, 0.f};
+      }
+    } else {
+      for (int t = lane; t < nct; t += WAVE) {   // rows past the end of the block: all padding
+        const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
+        Ent* dst = ent + coff[t] + qoff[t];
+        for (uint32_t k = 0; k < steps; ++k) dst[k * 4u + wave] = Ent{0u, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < qrows) {
+    const int64_t r = r0 + wave;
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    uint32_t* cnt = cnt_all + (size_t)wave * nct;
+    // batches of 64 entries in column order; within a batch the LDS atomic hands out the ranks of
+    // equal tiles (a fixed function of the input: the format is reproducible run to run)
+    // 8 batches are loaded ahead so that one memory round trip serves 512 entries
+    for (int64_t eb = e0; eb < e1; eb += 8 * WAVE) {
+      int c[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t e = eb + u * WAVE + lane;
+        c[u] = e < e1 ? idx[e] : -1;
+        v[u] = e < e1 ? val[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (c[u] >= 0) {
+          int i, t;
+          divmod_small(c[u], nct, inv_nct, i, t);
+          Ent x;
+          x.off = (uint32_t)i * (uint32_t)ldp_bytes;
+          x.val = v[u];
+          const uint32_t k = atomicAdd(&cnt[t], 1u);
+          if (staged) stage[lofs[t] + k * 4u + (uint32_t)wave] = x;
+          else ent[coff[t] + qoff[t] + k * 4u + (uint32_t)wave] = x;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (!staged) return;
+  __syncthreads();
+  for (int t = wave; t < nct; t += 4) {
+    const uint32_t lo = lofs[t], n = lofs[t + 1] - lo;
+    Ent* dst = ent + coff[t] + qoff[t];
+    for (uint32_t j = lane; j < n; j += WAVE) dst[j] = stage[lo + j];
+  }
+}
+
+// ---- rows whose entries are already grouped by tile (transpose_csr(..., tile_major_nct)) ----------
+// seg[r][t] = number of entries of row r in tiles < t: the tile of an entry (idx mod nct) is
+// non-decreasing along the row, so a binary search per boundary does it
+__global__ void tile_index_mod_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
+                                      int nct, float inv_nct, int32_t* __restrict__ seg) {
+  const int64_t total = rows * (int64_t)(nct + 1);
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; o < total; o += stride) {
+    const int64_t r = o / (nct + 1);
+    const int t = (int)(o - r * (nct + 1));
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    int64_t lo = e0, hi = e1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      int q, tm;
+      divmod_small(idx[mid], nct, inv_nct, q, tm);
+      if (tm < t) lo = mid + 1; else hi = mid;
+    }
+    seg[o] = (int32_t)(lo - e0);
+  }
+}
+
+// Streaming fill: a workgroup owns a quad; every (quad, tile) segment is four contiguous source runs
+// interleaved step by step ([k][g]) and padded with zero entries, written as one contiguous piece.
+__global__ void __launch_bounds__(256)
+quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+                      const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
+                      int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
+                      Ent* __restrict__ ent) {
+  extern __shared__ int32_t sg_lds[];   // [4][nct + 1] the quad's rows of seg
+  const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  if (4 * qd >= nrows) return;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int qrows = min(4, nrows - 4 * qd);
+  const int64_t r0 = (int64_t)row0 + 4 * qd;
+  for (int i = threadIdx.x; i < 4 * (nct + 1); i += 256) {
+    const int g = i / (nct + 1);
+    sg_lds[i] = g < qrows ? seg[(r0 + g) * (nct + 1) + (i - g * (nct + 1))] : 0;
+  }
+  __syncthreads();
+  const int g = lane & 3, k0 = lane >> 2;   // lane -> (step k0 + 16*pass, row g)
+  const int64_t base = g < qrows ? ptr[r0 + g] : 0;
+  const int32_t* mysg = sg_lds + g * (nct + 1);
+  const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
+  const uint32_t* __restrict__ qoff = quad_off + ((int64_t)rb * Q_BLOCK_QUADS + qd) * nct;
+  for (int t = wave; t < nct; t += 4) {
+    const int s0 = mysg[t], len = mysg[t + 1] - s0;
+    int qmax = max(len, __shfl_xor(len, 1));
+    qmax = max(qmax, __shfl_xor(qmax, 2));
+    Ent* dst = ent + coff[t] + qoff[t];
+    for (int k = k0; k < qmax; k += 16) {
+      Ent x{0u, 0.f};
+      if (k < len) {
+        const int64_t e = base + s0 + k;
+        int i, tm;
+        divmod_small(idx[e], nct, inv_nct, i, tm);
+        x.off = (uint32_t)i * (uint32_t)ldp_bytes;
+        x.val = val[e];
+      }
+      dst[k * 4 + g] = x;
+    }
   }
 }
 
@@ -868,7 +1049,8 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 }  // namespace
 
 // ---------------------------------------------------------------------------------- host side
-bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s) {
+bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
+                 bool rows_tile_major) {
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
   op = TiledOp();
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
@@ -904,7 +1086,10 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   int32_t* d_seg = nullptr;
   if (!transposed) {
     d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nct + 1));
-    if (quad) {
+    if (quad && rows_tile_major) {
+      hipLaunchKernelGGL(tile_index_mod_kernel, dim3(grid_for(S.rows * (int64_t)(nct + 1), 256, 16384)), dim3(256), 0, s,
+                         S.ptr, S.idx, S.rows, nct, inv_nct, d_seg);
+    } else if (quad) {
       hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(S.rows, 4, 8192)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                          S.ptr, S.idx, S.rows, nct, inv_nct, d_seg);
     } else {
@@ -977,7 +1162,13 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
   }
   Ent* d_ent = reinterpret_cast<Ent*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(Ent)));
-  SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
+  // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
+  // the direct fill over a zeroed buffer
+  const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
+                           (double)total <= 0.7 * QF_CAP * ((double)op_rows / 4.0) && nct <= 768;
+  const bool runs_fill = quad && !transposed && rows_tile_major && nct <= 4000;
+  if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(Ent), s));
+  else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
   uint32_t* run_global = nullptr;
   if (!quad && lds > 48 * 1024) {
@@ -987,6 +1178,14 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   if (transposed)
     hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+  else if (runs_fill)
+    hipLaunchKernelGGL(quad_fill_runs_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
+                       (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk, nct, inv_nct, ldp * 4,
+                       d_chunk, d_quad_off, d_ent);
+  else if (staged_fill)
+    hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
+                       (size_t)QF_CAP * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
+                       nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (quad)
     hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                        S.ptr, S.idx, S.val, S.rows, d_blk, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
@@ -1002,6 +1201,11 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
+}
+
+int tiled_tile_count(int64_t cols, int ldp) {
+  const int tc = Q_TILE_BYTES / (ldp * 4);
+  return (int)((cols + tc - 1) / tc);
 }
 
 void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,

@@ -491,11 +491,11 @@ def test_transposed_format_built_from_a_matches_the_one_built_from_the_transpose
     ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.05, k, seed=5, dtype=torch.float32))
     om = synth.gaussian_panel(n, k + p, 3).numpy()
     out = []
-    for from_at in (False, True):
-        if from_at:
-            monkeypatch.setenv("SAPCA_TILED_FROM_AT", "1")
+    for from_a in (False, True):
+        if from_a:
+            monkeypatch.setenv("SAPCA_TILED_FROM_A", "1")
         else:
-            monkeypatch.delenv("SAPCA_TILED_FROM_AT", raising=False)
+            monkeypatch.delenv("SAPCA_TILED_FROM_A", raising=False)
         pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
         t = pca.fit_transform(mat(ptr, idx, val, m, n))
         out.append((pca.singular_values_(np.float64), pca.components_(np.float64), t))
@@ -503,4 +503,33 @@ def test_transposed_format_built_from_a_matches_the_one_built_from_the_transpose
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])
     want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
+
+
+def test_staged_and_direct_format_fill_agree(monkeypatch):
+    """the LDS-staged builder of A's tile-major format and the direct one write the same bytes: bit-identical
+    fits; a matrix with a few very long rows sends some quads down the direct route inside the staged kernel"""
+    m, n, k, p, q = 5000, 3000, 10, 6, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.04, k, seed=8, dtype=torch.float32))
+    A = mat(ptr, idx, val, m, n).tolil()
+    rng = np.random.default_rng(0)
+    for r in (7, 1234, 4999):            # dense rows: 3000 entries each, a quad of > 6144 padded entries
+        A[r, :] = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    A = A.tocsr()
+    A.sort_indices()
+    om = synth.gaussian_panel(n, k + p, 3).numpy()
+    out = []
+    for direct in (False, True):
+        if direct:
+            monkeypatch.setenv("SAPCA_FILL_DIRECT", "1")
+        else:
+            monkeypatch.delenv("SAPCA_FILL_DIRECT", raising=False)
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(A)
+        out.append((pca.singular_values_(np.float64), t))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    A64 = A.astype(np.float64)
+    want = O.fit(A64.indptr.astype(np.int64), A64.indices.astype(np.int64), A64.data, m, n, n_components=k, n_oversamples=p,
+                 n_power_iterations=q, omega=om)
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
