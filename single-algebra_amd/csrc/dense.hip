@@ -39,23 +39,34 @@ gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ 
   for (int p = 0; p < NPAIR; ++p) acc[p] = d4{0, 0, 0, 0};
   const int64_t stride = (int64_t)gridDim.x * 4 * 4;
   int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
-  double v[NT], nxt[NT];
+  // D chunks of 4 rows in flight per wave: with one or two waves per SIMD the loop is otherwise bound by
+  // the HBM latency of a single 1 KiB chunk (0.6 TB/s measured with D = 1)
+  constexpr int D = 4;
+  T buf[D][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) nxt[t] = (r0 + g < rows) ? (double)P[(r0 + g) * ld + 16 * t + c] : 0.0;
-  for (; r0 < rows; r0 += stride) {
+  for (int d = 0; d < D; ++d) {
+    const int64_t r = r0 + d * stride + g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) v[t] = nxt[t];
-    const int64_t rn = r0 + stride + g;
+    for (int t = 0; t < NT; ++t) buf[d][t] = (r < rows) ? P[r * ld + 16 * t + c] : (T)0;
+  }
+  for (; r0 < rows; r0 += D * stride) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) nxt[t] = (rn < rows) ? (double)P[rn * ld + 16 * t + c] : 0.0;
-    int p = 0;
+    for (int d = 0; d < D; ++d) {
+      double v[NT];
 #pragma unroll
-    for (int ta = 0; ta < NT; ++ta)
+      for (int t = 0; t < NT; ++t) v[t] = (double)buf[d][t];
+      const int64_t rn = r0 + (d + D) * stride + g;
 #pragma unroll
-      for (int tb = ta; tb < NT; ++tb) {
-        acc[p] = mfma_f64(v[ta], v[tb], acc[p]);
-        ++p;
-      }
+      for (int t = 0; t < NT; ++t) buf[d][t] = (rn < rows) ? P[rn * ld + 16 * t + c] : (T)0;
+      int p = 0;
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < NT; ++tb) {
+          acc[p] = mfma_f64(v[ta], v[tb], acc[p]);
+          ++p;
+        }
+    }
   }
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
@@ -175,6 +186,98 @@ chol_inv_kernel(const double* __restrict__ G, int l, int ld, double* __restrict_
   if (tid == 0 && bad) atomicAdd(info, bad);
 }
 
+// The same factorisation for l <= 64 on ONE wave: lane i owns row i of L (left-looking:
+// L[i][j] = (G[i][j] - sum_{k<j} L[i][k] L[j][k]) / L[j][j]) and afterwards column i of L^-1 by forward
+// substitution.  Everything lives in LDS, column-major and unpadded (the lane-strided operand is then
+// conflict-free and the other one a broadcast); there is no workgroup barrier on the critical path,
+// and the loops stay rolled (a fully unrolled register version is no faster: ~80 KB of straight-line
+// code fetched once).  Measured 85 us for l = 60: ~28 us of per-step skeleton (shuffle, sqrt, divide),
+// ~27 us for each triangular phase's dot products at one wave's issue rate.
+__global__ void __launch_bounds__(64)
+chol_inv_wave_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
+                     int* __restrict__ info) {
+  constexpr int N = 64;
+  extern __shared__ double cw_lds[];
+  double* Lc = cw_lds;             // Lc[k*N + i] = L[i][k]
+  double* Xc = cw_lds + N * N;     // Xc[k*N + i] = (L^-1)[k][i]
+  double* dinvs = Xc + N * N;
+  const int i = threadIdx.x;
+  for (int k = 0; k < l; ++k) Lc[k * N + i] = (i < l && k <= i) ? G[(size_t)i * ld + k] : 0.0;
+  double dg = i < l ? fabs(G[(size_t)i * ld + i]) : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dg = fmax(dg, __shfl_xor(dg, off));
+  const double floor_s = dg * 1e-13 + 1e-300;
+  int bad = 0;
+  for (int j = 0; j < l; ++j) {
+    double s0 = Lc[j * N + i], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 15 < j; k += 16) {   // 32 LDS reads in flight per round trip: one wave has nothing else to hide the latency with
+      double p[16], q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { p[u] = Lc[(k + u) * N + i]; q[u] = Lc[(k + u) * N + j]; }
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        s0 -= p[u] * q[u];
+        s1 -= p[u + 1] * q[u + 1];
+        s2 -= p[u + 2] * q[u + 2];
+        s3 -= p[u + 3] * q[u + 3];
+      }
+    }
+    for (; k + 3 < j; k += 4) {
+      s0 -= Lc[k * N + i] * Lc[k * N + j];
+      s1 -= Lc[(k + 1) * N + i] * Lc[(k + 1) * N + j];
+      s2 -= Lc[(k + 2) * N + i] * Lc[(k + 2) * N + j];
+      s3 -= Lc[(k + 3) * N + i] * Lc[(k + 3) * N + j];
+    }
+    for (; k < j; ++k) s0 -= Lc[k * N + i] * Lc[k * N + j];
+    const double s = (s0 + s1) + (s2 + s3);
+    double piv = __shfl(s, j);
+    if (!(piv > floor_s)) { piv = floor_s; bad += 1; }
+    const double d = sqrt(piv), dinv = 1.0 / d;
+    Lc[j * N + i] = i == j ? d : (i > j ? s * dinv : 0.0);
+    if (i == j) dinvs[j] = dinv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // lane i: column i of L^-1:  x[i] = 1/L[i][i];  x[r] = -(sum_{i<=k<r} L[r][k] x[k]) / L[r][r]
+  for (int r = 0; r < l; ++r) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 15 < r; k += 16) {
+      double p[16], q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { p[u] = Lc[(k + u) * N + r]; q[u] = Xc[(k + u) * N + i]; }
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        s0 += p[u] * q[u];
+        s1 += p[u + 1] * q[u + 1];
+        s2 += p[u + 2] * q[u + 2];
+        s3 += p[u + 3] * q[u + 3];
+      }
+    }
+    for (; k + 3 < r; k += 4) {
+      s0 += Lc[k * N + r] * Xc[k * N + i];
+      s1 += Lc[(k + 1) * N + r] * Xc[(k + 1) * N + i];
+      s2 += Lc[(k + 2) * N + r] * Xc[(k + 2) * N + i];
+      s3 += Lc[(k + 3) * N + r] * Xc[(k + 3) * N + i];
+    }
+    for (; k < r; ++k) s0 += Lc[k * N + r] * Xc[k * N + i];
+    const double s = (s0 + s1) + (s2 + s3);
+    const double dinv = dinvs[r];
+    Xc[r * N + i] = r == i ? dinv : (r > i ? -s * dinv : 0.0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // R = L^T (upper): R[r][c] = L[c][r];  R^-1 = (L^-1)^T: Rinv[r][c] = (L^-1)[c][r]
+  for (int e = i; e < ld * ld; e += N) {
+    const int r = e / ld, c = e % ld;
+    const bool in = r < l && c < l && c >= r;
+    R[e] = in ? Lc[r * N + c] : 0.0;
+    Rinv[e] = in ? Xc[c * N + r] : 0.0;
+  }
+  if (i == 0 && bad) atomicAdd(info, bad);
+}
+
 // ---------------------------------------------------------------- panel GEMM
 template <typename T> struct Quad;
 template <> struct Quad<float> {
@@ -238,8 +341,19 @@ __global__ void colsum_partial_kernel(const T* __restrict__ P, int64_t rows, int
   extern __shared__ double red[];  // blockDim.y * ld
   const int j = threadIdx.x;
   double s = 0;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += (int64_t)gridDim.x * blockDim.y)
-    s += (w ? (double)w[r] : 1.0) * (double)P[r * ld + j];
+  const int64_t step = (int64_t)gridDim.x * blockDim.y;
+  int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
+  for (; r + 3 * step < rows; r += 4 * step) {   // four loads in flight; the sum keeps its order
+    const double a0 = (w ? (double)w[r] : 1.0) * (double)P[r * ld + j];
+    const double a1 = (w ? (double)w[r + step] : 1.0) * (double)P[(r + step) * ld + j];
+    const double a2 = (w ? (double)w[r + 2 * step] : 1.0) * (double)P[(r + 2 * step) * ld + j];
+    const double a3 = (w ? (double)w[r + 3 * step] : 1.0) * (double)P[(r + 3 * step) * ld + j];
+    s += a0;
+    s += a1;
+    s += a2;
+    s += a3;
+  }
+  for (; r < rows; r += step) s += (w ? (double)w[r] : 1.0) * (double)P[r * ld + j];
   red[threadIdx.y * ld + j] = s;
   __syncthreads();
   if (threadIdx.y == 0) {
@@ -396,7 +510,7 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
   const int nt = ld / 16;
   const int npair = nt * (nt + 1) / 2;
   int nblocks = (int)((rows + 15) / 16);
-  if (nblocks > 256) nblocks = 256;
+  if (nblocks > 512) nblocks = 512;
   if (nblocks < 1) nblocks = 1;
   double* slabs = scratch.as<double>((size_t)nblocks * npair * 256);
   switch (nt) {
@@ -414,6 +528,19 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
 }
 
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
+  static const bool general_only = getenv("SAPCA_CHOL_GENERAL") != nullptr;
+  if (l <= 64 && !general_only) {
+    constexpr int kWaveLds = (2 * 64 * 64 + 64) * (int)sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_wave_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds));
+      attr = true;
+    }
+    hipLaunchKernelGGL(chol_inv_wave_kernel, dim3(1), dim3(64), kWaveLds, s, G, l, ld, R, Rinv, info);
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
   const size_t lds = ((size_t)l * (l + 1) + l) * sizeof(double);
   static size_t attr_bytes = 0;
   if (lds > 48 * 1024 && lds > attr_bytes) {
@@ -448,7 +575,7 @@ void weighted_colsum(const T* P, int64_t rows, int ld, const T* w, T* out, DevBu
   int by = 256 / ld;
   if (by < 1) by = 1;
   int nblocks = (int)((rows + by * 8 - 1) / (by * 8));
-  if (nblocks > 256) nblocks = 256;
+  if (nblocks > 1024) nblocks = 1024;
   if (nblocks < 1) nblocks = 1;
   double* partial = scratch.as<double>((size_t)nblocks * ld);
   hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(nblocks), dim3(ld, by), (size_t)by * ld * sizeof(double), s, P,
