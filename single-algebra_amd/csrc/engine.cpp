@@ -9,6 +9,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -331,7 +332,11 @@ void Engine<T>::fit_randomized(H& h) {
         for (int t = i; t <= j; ++t) acc += r2[(size_t)i * ld + t] * r1[(size_t)t * ld + j];
         Rz[(size_t)i * l + j] = acc;
       }
+    const auto tj0 = std::chrono::steady_clock::now();
     jacobi_svd(Rz, l, Ur, sv);
+    if (h.opt.verbose)
+      fprintf(stderr, "sapca: host Jacobi SVD of the %d x %d factor: %.3f ms\n", l, l,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count());
     for (int i = 0; i < l; ++i)
       SAPCA_CHECK(std::isfinite(sv[i]), SAPCA_ERR_SVD, "Randomized SVD computation failed: non-finite singular value");
     const int ldk = (int)round_up(k, 16);
