@@ -51,7 +51,8 @@ __global__ void expand_rows_kernel(const int64_t* __restrict__ ptr, int64_t rows
 }
 
 // ptr[j] = first position in the ascending key array with key >= j, j in [0, nkeys].
-__global__ void lower_bound_kernel(const uint32_t* __restrict__ keys, int64_t count, int64_t nkeys,
+template <typename K>
+__global__ void lower_bound_kernel(const K* __restrict__ keys, int64_t count, int64_t nkeys,
                                    int64_t* __restrict__ ptr) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j > nkeys) return;
@@ -103,9 +104,10 @@ __global__ void permuted_len_kernel(const int64_t* __restrict__ ptr, int64_t row
   if (r < rows) lenp[tile_major_rank(r, rows, nct)] = ptr[r + 1] - ptr[r];
   if (r == 0) lenp[rows] = 0;
 }
+template <typename K>
 __global__ void pack_rows_permuted_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                           const float* __restrict__ val, int64_t rows, int nct,
-                                          const int64_t* __restrict__ pptr, uint32_t* __restrict__ keys,
+                                          const int64_t* __restrict__ pptr, K* __restrict__ keys,
                                           uint64_t* __restrict__ packed) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
@@ -114,7 +116,7 @@ __global__ void pack_rows_permuted_kernel(const int64_t* __restrict__ ptr, const
     const int64_t e0 = ptr[r], e1 = ptr[r + 1];
     const int64_t d0 = pptr[tile_major_rank(r, rows, nct)] - e0;
     for (int64_t e = e0 + lane; e < e1; e += WAVE) {
-      keys[d0 + e] = (uint32_t)idx[e];
+      keys[d0 + e] = (K)idx[e];
       packed[d0 + e] = ((uint64_t)(uint32_t)r << 32) | (uint64_t)__float_as_uint(val[e]);
     }
   }
@@ -341,16 +343,35 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
                          tile_major_nct, pptr);
       SAPCA_HIP(rocprim::exclusive_scan(tmp, scan_bytes, pptr, pptr, (int64_t)0, (size_t)A.rows + 1,
                                         rocprim::plus<int64_t>(), s));
-      hipLaunchKernelGGL(pack_rows_permuted_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,
-                         reinterpret_cast<const float*>(A.val), A.rows, tile_major_nct, pptr, keys_in, packed);
+      if (bits <= 16) {
+        // the keys are written here anyway: 16-bit ones make every sort pass move 10 instead of 12 bytes per entry
+        uint16_t* k16_in = reinterpret_cast<uint16_t*>(keys_in);
+        uint16_t* k16_out = reinterpret_cast<uint16_t*>(keys_out);
+        size_t sort16 = 0;
+        SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sort16, (const uint16_t*)nullptr, (uint16_t*)nullptr,
+                                            (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
+        SAPCA_CHECK(sort16 <= std::max(sort_bytes, scan_bytes) + 256, SAPCA_ERR_NOMEM, "transpose: sort scratch too small");
+        hipLaunchKernelGGL((pack_rows_permuted_kernel<uint16_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s,
+                           A.ptr, A.idx, reinterpret_cast<const float*>(A.val), A.rows, tile_major_nct, pptr, k16_in, packed);
+        SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort16, k16_in, k16_out, packed, packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+        hipLaunchKernelGGL((lower_bound_kernel<uint16_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, k16_out,
+                           nnz, A.cols, t_ptr);
+      } else {
+        hipLaunchKernelGGL((pack_rows_permuted_kernel<uint32_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s,
+                           A.ptr, A.idx, reinterpret_cast<const float*>(A.val), A.rows, tile_major_nct, pptr, keys_in, packed);
+        SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, keys_in, keys_out, packed, packed_out, (size_t)nnz, 0u,
+                                            (unsigned)bits, s));
+        hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out,
+                           nnz, A.cols, t_ptr);
+      }
     } else {
       hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr,
                          reinterpret_cast<const float*>(A.val), A.rows, packed);
+      SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, reinterpret_cast<const uint32_t*>(A.idx), keys_out, packed,
+                                          packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+      hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out,
+                         nnz, A.cols, t_ptr);
     }
-    SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, permuted ? keys_in : reinterpret_cast<const uint32_t*>(A.idx),
-                                        keys_out, packed, packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
-    hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out, nnz,
-                       A.cols, t_ptr);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, packed_out, nnz, t_idx,
                        reinterpret_cast<float*>(t_val));
     SAPCA_HIP(hipGetLastError());
@@ -369,7 +390,7 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
   hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.rows, rowid);
   SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sort_bytes, reinterpret_cast<const uint32_t*>(A.idx), keys_out, iota, perm,
                                       (size_t)nnz, 0u, (unsigned)bits, s));
-  hipLaunchKernelGGL(lower_bound_kernel, dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out, nnz,
+  hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out, nnz,
                      A.cols, t_ptr);
   hipLaunchKernelGGL((gather_transposed_kernel<T>), dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, perm, rowid,
                      A.val, nnz, t_idx, t_val);
