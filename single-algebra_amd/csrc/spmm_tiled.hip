@@ -509,7 +509,7 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 // 8-byte store per entry, which is what it spends its time on.  Quads larger than the LDS image
 // (very long rows) take the direct route and zero their padding themselves, so the entry buffer
 // needs no memset on this path.
-constexpr int QF_CAP = 6144;   // entries of one quad staged in LDS (48 KiB)
+constexpr int QF_CAP = 4096;   // entries of one quad staged in LDS (32 KiB)
 __global__ void __launch_bounds__(256)
 quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                         const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
@@ -1165,7 +1165,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
   const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
-                           (double)total <= 0.7 * QF_CAP * ((double)op_rows / 4.0) && nct <= 768;
+                           (double)total <= 0.85 * QF_CAP * ((double)op_rows / 4.0) && nct <= 768;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= 4000;
   if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(Ent), s));
   else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
