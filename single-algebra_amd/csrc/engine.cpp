@@ -109,13 +109,17 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   const bool at_tile_major = tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
 
   CsrView<T> At;
+  const uint64_t* at_packed = nullptr;
   {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
     int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* at_val = h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
     // rows of A^T grouped by the interleaved tile of the A row they came from: its format fill streams
-    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp) : 0);
+    // unmasked: the statistics and the format builder read the sort's packed rows directly and the
+    // unpack pass into (at_idx, at_val) is skipped (done lazily below if the row kernel has to take over)
+    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp) : 0,
+                     (at_tile_major && !masked && getenv("SAPCA_AT_UNPACK") == nullptr) ? &at_packed : nullptr);
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
   }
 
@@ -124,7 +128,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   {
     Scope sc(h, C_STATS);
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
-    k::row_sums(At, d_stats, d_stats + n, s);
+    if (at_packed) k::row_sums_packed(At.ptr, at_packed, n, d_stats, d_stats + n, s);
+    else k::row_sums(At, d_stats, d_stats + n, s);
     k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
     const double m_local = (double)m;
     SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &m_local, sizeof(double), hipMemcpyHostToDevice, s));
@@ -197,8 +202,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
       const bool ok_a = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
-      const bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
-                                  k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major));
+      bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
+                            k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed));
+      if (at_packed && !ok_at) {   // someone needs the transposed CSR after all
+        k::unpack_transposed(at_packed, nnz, const_cast<int32_t*>(At.idx), reinterpret_cast<float*>(const_cast<T*>(At.val)), s);
+        at_packed = nullptr;
+        ok_at = ok_a && k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major);
+      }
       if (h.opt.verbose)
         fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
                 ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,

@@ -13,7 +13,11 @@ void narrow_indices(const uint64_t* ptr64, const uint64_t* idx64, int64_t m, int
 // CSR(A) -> CSR(A^T), entries of each A^T row in ascending A-row order (stable, deterministic).
 template <typename T>
 void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val, DevBuf& scratch, hipStream_t s,
-                   int tile_major_nct = 0);   // f32, > 1: entries of a transposed row ordered by (row mod nct, row / nct)
+                   int tile_major_nct = 0,   // f32, > 1: entries of a transposed row ordered by (row mod nct, row / nct)
+                   const uint64_t** packed_rows_out = nullptr);   // with tile_major_nct: leave the rows packed as
+                                                                   // (row << 32 | value bits) in `scratch`, skip t_idx / t_val
+void unpack_transposed(const uint64_t* packed, int64_t nnz, int32_t* t_idx, float* t_val, hipStream_t s);
+void row_sums_packed(const int64_t* ptr, const uint64_t* packed, int64_t rows, double* sum, double* sumsq, hipStream_t s);
 // Row sums of a CSR (applied to A^T: the reference's sum_col / sum_col_squared), f64 accumulation.
 template <typename T>
 void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s);
@@ -52,7 +56,8 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
 // format cannot be built (the caller stays on the row kernel)
 // rows_tile_major: S's rows were produced by transpose_csr(..., tile_major_nct = tiled_tile_count(S.cols, ldp))
 bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                 bool rows_tile_major = false);
+                 bool rows_tile_major = false, const uint64_t* packed_rows = nullptr);   // packed_rows: S.idx / S.val are not
+                                                                                          // filled, read (row << 32 | value) instead
 // number of interleaved column tiles the format uses for an operator with `cols` columns
 int tiled_tile_count(int64_t cols, int ldp);
 void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,

@@ -622,8 +622,9 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
 // ---- rows whose entries are already grouped by tile (transpose_csr(..., tile_major_nct)) ----------
 // seg[r][t] = number of entries of row r in tiles < t: the tile of an entry (idx mod nct) is
 // non-decreasing along the row, so a binary search per boundary does it
-__global__ void tile_index_mod_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
-                                      int nct, float inv_nct, int32_t* __restrict__ seg) {
+__global__ void tile_index_mod_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                      const uint64_t* __restrict__ packed, int64_t rows, int nct, float inv_nct,
+                                      int32_t* __restrict__ seg) {
   const int64_t total = rows * (int64_t)(nct + 1);
   int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -635,7 +636,7 @@ __global__ void tile_index_mod_kernel(const int64_t* __restrict__ ptr, const int
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       int q, tm;
-      divmod_small(idx[mid], nct, inv_nct, q, tm);
+      divmod_small(packed ? (int)(packed[mid] >> 32) : idx[mid], nct, inv_nct, q, tm);
       if (tm < t) lo = mid + 1; else hi = mid;
     }
     seg[o] = (int32_t)(lo - e0);
@@ -646,7 +647,7 @@ __global__ void tile_index_mod_kernel(const int64_t* __restrict__ ptr, const int
 // interleaved step by step ([k][g]) and padded with zero entries, written as one contiguous piece.
 __global__ void __launch_bounds__(256)
 quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
-                      const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
+                      const uint64_t* __restrict__ packed, const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
                       int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
                       Ent* __restrict__ ent) {
   extern __shared__ int32_t sg_lds[];   // [4][nct + 1] the quad's rows of seg
@@ -675,10 +676,18 @@ quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
       Ent x{0u, 0.f};
       if (k < len) {
         const int64_t e = base + s0 + k;
+        int c;
+        if (packed) {
+          const uint64_t pv = packed[e];
+          c = (int)(pv >> 32);
+          x.val = __uint_as_float((uint32_t)pv);
+        } else {
+          c = idx[e];
+          x.val = val[e];
+        }
         int i, tm;
-        divmod_small(idx[e], nct, inv_nct, i, tm);
+        divmod_small(c, nct, inv_nct, i, tm);
         x.off = (uint32_t)i * (uint32_t)ldp_bytes;
-        x.val = val[e];
       }
       dst[k * 4 + g] = x;
     }
@@ -1050,7 +1059,7 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 
 // ---------------------------------------------------------------------------------- host side
 bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                 bool rows_tile_major) {
+                 bool rows_tile_major, const uint64_t* packed_rows) {
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
   op = TiledOp();
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
@@ -1060,6 +1069,8 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   const bool quad = fmt_env == 1;   // 1: a row per 16-lane group (default); 0: two half-waves per row
   const int tc = (quad ? Q_TILE_BYTES : TILE_BYTES) / (ldp * 4);
   if (transposed && (!quad || (tc + 63) / 64 > TQ_NI)) return false;
+  if (rows_tile_major && !quad) return false;
+  if (packed_rows && !(quad && !transposed && rows_tile_major)) return false;   // only the tile-major builders read packed rows
   const int nct = (int)((op_cols + tc - 1) / tc);
   const int maskw = (tc + 31) / 32;
   // row blocks of <= 512 rows.  With enough rows the block count is a multiple of the 256 CUs (every
@@ -1088,7 +1099,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
     d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nct + 1));
     if (quad && rows_tile_major) {
       hipLaunchKernelGGL(tile_index_mod_kernel, dim3(grid_for(S.rows * (int64_t)(nct + 1), 256, 16384)), dim3(256), 0, s,
-                         S.ptr, S.idx, S.rows, nct, inv_nct, d_seg);
+                         S.ptr, S.idx, packed_rows, S.rows, nct, inv_nct, d_seg);
     } else if (quad) {
       hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(S.rows, 4, 8192)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                          S.ptr, S.idx, S.rows, nct, inv_nct, d_seg);
@@ -1167,6 +1178,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
                            (double)total <= 0.85 * QF_CAP * ((double)op_rows / 4.0) && nct <= 768;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= 4000;
+  if (packed_rows && !runs_fill) return false;
   if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(Ent), s));
   else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
@@ -1180,8 +1192,8 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (runs_fill)
     hipLaunchKernelGGL(quad_fill_runs_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
-                       (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk, nct, inv_nct, ldp * 4,
-                       d_chunk, d_quad_off, d_ent);
+                       (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, nct, inv_nct,
+                       ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (staged_fill)
     hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)QF_CAP * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,

@@ -484,24 +484,26 @@ def test_transform_of_a_matrix_that_was_not_fitted(dtype):
                       sp.csr_matrix((10, n + 1), dtype=dtype))
 
 
-def test_transposed_format_built_from_a_matches_the_one_built_from_the_transposed_csr(monkeypatch):
-    """A^T's tile-major format is built straight from A; building it from the device-made transposed CSR
-    instead must give the same bytes, hence bit-identical fits"""
+def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
+    """A^T's tile-major format can come from the tile-major transposed rows still packed by the sort (default),
+    from the same rows unpacked into a CSR, from a naturally ordered transposed CSR, or straight from A: the
+    bytes are the same, hence bit-identical fits"""
     m, n, k, p, q = 6000, 1500, 12, 6, 2
     ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.05, k, seed=5, dtype=torch.float32))
     om = synth.gaussian_panel(n, k + p, 3).numpy()
     out = []
-    for from_a in (False, True):
-        if from_a:
-            monkeypatch.setenv("SAPCA_TILED_FROM_A", "1")
-        else:
-            monkeypatch.delenv("SAPCA_TILED_FROM_A", raising=False)
+    routes = (None, "SAPCA_AT_UNPACK", "SAPCA_AT_NATURAL", "SAPCA_TILED_FROM_A")
+    for route in routes:
+        for r in routes[1:]:
+            monkeypatch.delenv(r, raising=False)
+        if route:
+            monkeypatch.setenv(route, "1")
         pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
         t = pca.fit_transform(mat(ptr, idx, val, m, n))
-        out.append((pca.singular_values_(np.float64), pca.components_(np.float64), t))
-    np.testing.assert_array_equal(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    np.testing.assert_array_equal(out[0][2], out[1][2])
+        out.append((pca.singular_values_(np.float64), pca.components_(np.float64), t, pca.mean_(np.float64)))
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            np.testing.assert_array_equal(a, b)
     want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
 
