@@ -1,29 +1,29 @@
-// LDS-staged sparse x dense-panel sweep (f32) and the tile-major operator format it reads.
+// LDS-staged sparse x dense-panel sweep (f32) and the tile-major operator formats it reads.
 //
 // Why: per stored entry the sweep reads 8 B of A but a whole panel row (256 B at l = 60).  Served
 // from L2 that gather caps the sweep far below the HBM roofline (measured 5.8 % with
 // the row kernel of spmm.hip).  Here the panel rows of one column tile are staged in LDS once per
 // workgroup and every gather is an LDS read, while A streams from HBM exactly once, contiguously.
 //
-// Operator format ("tile-major", built once per fit by build_tiled()):
-//   rows are cut into `nrb` blocks of <= 512 rows (one workgroup: 16 waves x <= 32 rows), columns
-//   into `nct` tiles of TC panel rows (96 KiB of LDS).  For every (row block, column tile) the
-//   entries are stored contiguously -- wave 0's rows first, row after row, each row's segment
-//   padded with {0, 0.0f} to an even number of entries (one wave-step consumes two).  An entry is
-//   {u32 byte offset of its panel row inside the LDS tile, f32 value}; a u8 table holds the number
-//   of steps of every (row, tile) segment.
+// Two formulations live in this file (DESIGN.md §5 has the measurements that led from one to the other):
 //
-// Kernel (1024 threads, one workgroup per CU because of the 160 KiB of LDS):
-//   per column tile:  barrier; panel tile + the block's entry chunk -> LDS (both contiguous in HBM,
-//   prefetched into registers during the previous tile's compute); barrier; every wave walks its
-//   rows.  The two half-waves take two consecutive entries of the row per step: each lane reads
-//   its half's entry from the staged chunk (ds_read_b64, two distinct addresses per wave), then
-//   its LDP/32 columns of that entry's panel row (ds_read_b64 / b128, conflict-free: a panel row
-//   spans all 64 banks) and FMAs them into the row's accumulator (LDP/32 VGPRs).  Half-waves rather
-//   than four quarter-waves keep the accumulator redundancy at 2x, so 512 rows share one staged
-//   tile; wave-uniform entries (v_readlane, measured) cost ~6x more than this per-lane read.
-//   Accumulators stay in VGPRs across all column tiles; the halves are summed at the end.  Tile ranges can be split over workgroups
-//   (A^T has few rows): partial sums go to a slab that a second kernel adds in fixed order.
+//  * "quad" (default; second half of the file): rows in blocks of <= 512 (one workgroup of 16 waves),
+//    columns in `nct` INTERLEAVED tiles (tile t = columns == t mod nct, 80 KiB of LDS).  A wave is four
+//    groups of 16 lanes and every group walks its own row with ds_read_b128; four consecutive rows (a
+//    quad) advance in lockstep, so the format stores a quad's segment step by step, 4 entries per step,
+//    padded with {0, 0.0f} to its longest row.  8 quads per wave, accumulators in VGPRs across all tiles,
+//    no cross-lane reduction.  Builders: histogram/index + count + fill (LDS-staged for A, streaming for
+//    the tile-major rows of A^T, direct scatter as the fallback), or A^T straight from A (tquad_*).
+//
+//  * "pair" (SAPCA_TILED_FMT=0; first half): contiguous column tiles of 96 KiB; the two half-waves of a
+//    wave take two consecutive entries of ONE row per step (ds_read_b64), accumulators duplicated in the
+//    two halves and summed at the end.  1.47 ms per C2 sweep against 0.89 ms for the quad kernel; kept
+//    for A/B runs and because its ablation switches (SAPCA_ABL) document how the numbers were obtained.
+//
+// Common to both: an entry is {u32 byte offset of its panel row inside the LDS tile, f32 value}; per
+// column tile the workgroup does  barrier; panel tile + the block's entry chunk -> LDS (both prefetched
+// into registers during the previous tile's compute); barrier; compute.  Tile ranges can be split over
+// workgroups (A^T has few rows): partial sums go to a slab that a second kernel adds in fixed order.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
