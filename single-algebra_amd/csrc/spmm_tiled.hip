@@ -357,12 +357,15 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 // the end, and the accumulators of a 512-row block take 32 VGPRs instead of 64.  The four rows of
 // a quad advance in lockstep: the format pads every quad's segment in a tile to its longest row
 // (zero entries: offset 0, value 0).
-constexpr int QGROUPS = 4, QLANES = WAVE / QGROUPS, QWAVES = 16, QTHREADS = QWAVES * WAVE;
+#ifndef SAPCA_QWAVES
+#define SAPCA_QWAVES 16   // waves per workgroup of the quad sweep: 16 x 8 quads, or 8 x 16 quads with 8-step batches
+#endif
+constexpr int QGROUPS = 4, QLANES = WAVE / QGROUPS, QWAVES = SAPCA_QWAVES, QTHREADS = QWAVES * WAVE;
 constexpr int Q_TILE_BYTES = 80 * 1024;
 constexpr int Q_STAGE_BYTES = LDS_TOTAL - Q_TILE_BYTES - 1024;
 constexpr int Q_STAGE_ENTRIES = Q_STAGE_BYTES / 8 - WAVE;
 constexpr int Q_BLOCK_QUADS = BLOCK_ROWS / 4;   // stride of the per-chunk quad step table
-constexpr int q_rows_per_group(int ldp) { return ldp == 64 ? 8 : 4; }
+constexpr int q_rows_per_group(int ldp) { return (ldp == 64 ? 128 : 64) / QWAVES; }
 // quads (4 consecutive rows) of a block are dealt to its 16 waves in contiguous, balanced ranges
 __host__ __device__ inline int q_first(int wave, int nquads) { return wave * nquads / QWAVES; }
 
@@ -978,6 +981,13 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const in
 #pragma unroll
       for (int j = 0; j < RG; ++j) {
         int n = __builtin_amdgcn_readlane(cnt_v, j);
+        if constexpr (QWAVES == 8 && NV == 1) {   // 256 VGPRs per lane: 8 steps in flight per wave
+          while (n >= 8) {
+            quad_batch<NV, 8>(acc[j], sl, tl);
+            sl += 8 * QGROUPS * 8;
+            n -= 8;
+          }
+        }
         while (n >= 4) {
           quad_batch<NV, 4>(acc[j], sl, tl);
           sl += 4 * QGROUPS * 8;
