@@ -270,7 +270,7 @@ void Engine<T>::fit_randomized(H& h) {
   const bool center = h.opt.center != 0;
   const int variant = h.opt.spmm_variant;
 
-  T* X = h.panel_x.as<T>((size_t)std::max<int64_t>(n_used, 1) * ld);
+  T* X = h.panel_x.as<T>(((size_t)std::max<int64_t>(n_used, 1) + 1) * ld);   // + one row: the column sums ride along in the all-reduce
   T* Y = h.panel_y.as<T>((size_t)std::max<int64_t>(m, 1) * ld);
   double* small = h.small.as<double>(kSmallDoubles);
   double* R1 = small + (size_t)3 * ld * ld;
@@ -307,12 +307,11 @@ void Engine<T>::fit_randomized(H& h) {
       Scope sc(h, C_SPMMT);
       k::spmm(At, &h.tiled_at, Y, ld, X, ld, ld, (const T*)nullptr, variant, h.split_scratch, s);
     }
-    if (h.comm.active()) h.comm.allreduce(X, (uint64_t)n_used * ld, kDtype, s);
-    if (center) {
-      k::weighted_colsum(Y, m, ld, (const T*)nullptr, svec, h.scratch2, s);
-      if (h.comm.active()) h.comm.allreduce(svec, (uint64_t)ld, kDtype, s);
-      k::rank1_subtract(X, n_used, ld, mu, svec, s);
-    }
+    // one collective per sweep: the l column sums of this rank's Y sit in the row after the panel
+    T* sv = h.comm.active() ? X + (size_t)n_used * ld : svec;
+    if (center) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
+    if (h.comm.active()) h.comm.allreduce(X, (uint64_t)n_used * ld + (center ? (uint64_t)ld : 0), kDtype, s);
+    if (center) k::rank1_subtract(X, n_used, ld, mu, sv, s);
   };
 
   for (int it = 0; it < q; ++it) {
