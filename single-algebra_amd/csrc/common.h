@@ -82,6 +82,7 @@ struct TiledOp {
   int nsplit = 1, tiles_per_split = 0;
   int slots = 2;            // lane groups per wave the entry stream was padded for
   int fmt = 0;              // 0: two half-waves share a row; 1: "quad", one row per 16-lane group
+  int tile_bytes = 0;       // LDS bytes of one panel tile (the entry staging takes the rest of the 160 KiB)
   const int32_t* blk_row0 = nullptr;   // [nrb+1]
   const int64_t* chunk_off = nullptr;  // [nrb*nct+1] entry offsets
   const uint32_t* wave_off = nullptr;  // [nrb*nct][8]

@@ -56,8 +56,8 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
 // format cannot be built (the caller stays on the row kernel)
 // rows_tile_major: S's rows were produced by transpose_csr(..., tile_major_nct = tiled_tile_count(S.cols, ldp))
 bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                 bool rows_tile_major = false, const uint64_t* packed_rows = nullptr);   // packed_rows: S.idx / S.val are not
-                                                                                          // filled, read (row << 32 | value) instead
+                 bool rows_tile_major = false, const uint64_t* packed_rows = nullptr,   // packed_rows: S.idx / S.val are not
+                 bool allow_big_tile = true);                                            // filled, read (row << 32 | value) instead
 // number of interleaved column tiles the format uses for an operator with `cols` columns
 int tiled_tile_count(int64_t cols, int ldp);
 void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,

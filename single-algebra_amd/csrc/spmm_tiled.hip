@@ -361,9 +361,10 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 #define SAPCA_QWAVES 16   // waves per workgroup of the quad sweep: 16 x 8 quads, or 8 x 16 quads with 8-step batches
 #endif
 constexpr int QGROUPS = 4, QLANES = WAVE / QGROUPS, QWAVES = SAPCA_QWAVES, QTHREADS = QWAVES * WAVE;
-constexpr int Q_TILE_BYTES = 80 * 1024;
-constexpr int Q_STAGE_BYTES = LDS_TOTAL - Q_TILE_BYTES - 1024;
-constexpr int Q_STAGE_ENTRIES = Q_STAGE_BYTES / 8 - WAVE;
+constexpr int Q_TILE_BYTES = 80 * 1024;          // default split of the 160 KiB: 80 KiB panel tile + 79 KiB entry staging
+constexpr int Q_TILE_BYTES_BIG = 96 * 1024;      // for operators whose chunks leave room: fewer, longer tile steps
+constexpr int q_stage_bytes(int tile_bytes) { return LDS_TOTAL - tile_bytes - 1024; }
+constexpr int q_stage_entries(int tile_bytes) { return q_stage_bytes(tile_bytes) / 8 - WAVE; }
 constexpr int Q_BLOCK_QUADS = BLOCK_ROWS / 4;   // stride of the per-chunk quad step table
 constexpr int q_rows_per_group(int ldp) { return (ldp == 64 ? 128 : 64) / QWAVES; }
 // quads (4 consecutive rows) of a block are dealt to its 16 waves in contiguous, balanced ranges
@@ -929,7 +930,7 @@ __device__ __forceinline__ void load_tile_interleaved(v4f (&r)[N], const float* 
     woff_next = wave_off[cidx_ * QWAVES + wave];                                                    \
   }
 
-template <int LDP, bool PREFETCH>
+template <int LDP, bool PREFETCH, int TILE_B>
 __global__ void __launch_bounds__(QTHREADS)
 spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const int64_t* __restrict__ chunk_off,
                  const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, const Ent* __restrict__ ent,
@@ -938,10 +939,11 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const in
                  int mode) {
   constexpr int NV = LDP / 64;            // b128 reads per panel row per lane
   constexpr int RG = q_rows_per_group(LDP);
-  constexpr int NP_TILE = Q_TILE_BYTES / (QTHREADS * 16), NP_STAGE = (Q_STAGE_BYTES + QTHREADS * 16 - 1) / (QTHREADS * 16);
+  constexpr int STAGE_B = q_stage_bytes(TILE_B);
+  constexpr int NP_TILE = TILE_B / (QTHREADS * 16), NP_STAGE = (STAGE_B + QTHREADS * 16 - 1) / (QTHREADS * 16);
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* tile = lds;
-  char* stage = lds + Q_TILE_BYTES;
+  char* stage = lds + TILE_B;
   const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
@@ -967,8 +969,8 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const in
     if (!(mode & 8) || ct == ct0) {
       __syncthreads();  // the previous tile's readers are done
       if (!PREFETCH) SAPCA_QPREFETCH(ct)
-      store_regs<NP_TILE, QTHREADS>(pt, tile, Q_TILE_BYTES);
-      store_regs<NP_STAGE, QTHREADS>(ps, stage, Q_STAGE_BYTES);
+      store_regs<NP_TILE, QTHREADS>(pt, tile, TILE_B);
+      store_regs<NP_STAGE, QTHREADS>(ps, stage, STAGE_B);
       __syncthreads();
     }
     const int cnt_v = cnt_next;
@@ -1035,16 +1037,16 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const in
 #undef SAPCA_QPREFETCH
 #undef SAPCA_QBOOKKEEPING
 
-template <int LDP, bool PREFETCH>
+template <int LDP, bool PREFETCH, int TILE_B>
 void launch_quad(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
                  hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_quad_kernel<LDP, PREFETCH>),
+    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_quad_kernel<LDP, PREFETCH, TILE_B>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     attr = true;
   }
-  hipLaunchKernelGGL((spmm_quad_kernel<LDP, PREFETCH>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
+  hipLaunchKernelGGL((spmm_quad_kernel<LDP, PREFETCH, TILE_B>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
                      op.blk_row0, op.nct, op.tc, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
                      reinterpret_cast<const Ent*>(op.ent), op.cols, X, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
                      ncols, cvec, mode);
@@ -1069,7 +1071,7 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 
 // ---------------------------------------------------------------------------------- host side
 bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                 bool rows_tile_major, const uint64_t* packed_rows) {
+                 bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile) {
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
   op = TiledOp();
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
@@ -1077,12 +1079,13 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   const int64_t op_rows = transposed ? S.cols : S.rows, op_cols = transposed ? S.rows : S.cols;
   static const int fmt_env = getenv("SAPCA_TILED_FMT") ? atoi(getenv("SAPCA_TILED_FMT")) : 1;
   const bool quad = fmt_env == 1;   // 1: a row per 16-lane group (default); 0: two half-waves per row
-  const int tc = (quad ? Q_TILE_BYTES : TILE_BYTES) / (ldp * 4);
+  int tile_bytes = quad ? Q_TILE_BYTES : TILE_BYTES;
+  int tc = tile_bytes / (ldp * 4);
   if (transposed && (!quad || (tc + 63) / 64 > TQ_NI)) return false;
   if (rows_tile_major && !quad) return false;
   if (packed_rows && !(quad && !transposed && rows_tile_major)) return false;   // only the tile-major builders read packed rows
-  const int nct = (int)((op_cols + tc - 1) / tc);
-  const int maskw = (tc + 31) / 32;
+  int nct = (int)((op_cols + tc - 1) / tc);
+  const int maskw = (Q_TILE_BYTES / (ldp * 4) + 31) / 32;   // only the transposed builder uses it (default split)
   // row blocks of <= 512 rows.  With enough rows the block count is a multiple of the 256 CUs (every
   // CU runs the same number of workgroups); with few rows (A^T) the tile range is split instead.
   static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
@@ -1090,7 +1093,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   const int waves = quad ? QWAVES : waves_for(slots);
   const int block_rows = quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
                               : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
-  const int stage_cap = quad ? Q_STAGE_ENTRIES : STAGE_ENTRIES;
+  int stage_cap = quad ? q_stage_entries(tile_bytes) : STAGE_ENTRIES;
   int64_t nrb = (op_rows + block_rows - 1) / block_rows;
   int nsplit = 1;
   if (nrb >= 192) {
@@ -1101,6 +1104,20 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
     nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, 512 / nrb));
     const int64_t nrb_fit = 512 / nsplit;
     if (nrb_fit >= nrb && nrb_fit <= op_rows) nrb = nrb_fit;
+  }
+  // the bigger tile (fewer, longer tile steps, less quad padding) when the chunks are expected to leave room
+  // in the smaller staging area; operators fed by the tile-major transposition keep the default split
+  // (their tile count is fixed before the transposition runs)
+  if (quad && !transposed && !rows_tile_major && allow_big_tile && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
+    const int tcb = Q_TILE_BYTES_BIG / (ldp * 4);
+    const double est = 1.3 * (double)S.nnz / ((double)nrb * std::ceil((double)op_cols / tcb));
+    if (est <= 0.78 * q_stage_entries(Q_TILE_BYTES_BIG)) {
+      tile_bytes = Q_TILE_BYTES_BIG;
+      tc = tcb;
+      nct = (int)((op_cols + tc - 1) / tc);
+      stage_cap = q_stage_entries(tile_bytes);
+      if (nsplit > 1) nsplit = (int)std::min<int64_t>(nct, nsplit);
+    }
   }
   if (quad && !transposed && (op_cols >= (1 << 24) || nct > 4096)) return false;   // float-reciprocal tile arithmetic, LDS tables of the builder
   const float inv_nct = 1.0f / (float)nct;
@@ -1178,6 +1195,8 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
               transposed ? " (transposed source)" : "", (long long)op_rows, (long long)op_cols, (long long)nrb, nct, nsplit,
               (long long)max_chunk, stage_cap, (long long)total);
     if (max_chunk <= stage_cap) break;
+    if (tile_bytes == Q_TILE_BYTES_BIG)   // the estimate was too optimistic: take the default split instead of halving the row blocks
+      return build_tiled(S, transposed, ldp, op, buf, s, rows_tile_major, packed_rows, false);
     if (attempt == 3 || nrb * 2 > op_rows) return false;  // does not fit: the caller stays on the row kernel
     nrb *= 2;
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
@@ -1219,7 +1238,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   SAPCA_HIP(hipGetLastError());
   op.rows = op_rows; op.cols = op_cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
-  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0;
+  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
   op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
@@ -1246,9 +1265,13 @@ void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols,
   }
   const bool pf = !(mode & 4);
   if (op.fmt == 1) {
-    if (op.ldp == 64 && pf) launch_quad<64, true>(op, X, out, ldo, nc, cvec, mode, s);
-    else if (op.ldp == 64) launch_quad<64, false>(op, X, out, ldo, nc, cvec, mode, s);
-    else launch_quad<128, false>(op, X, out, ldo, nc, cvec, mode, s);
+    const bool big = op.tile_bytes == Q_TILE_BYTES_BIG;
+    if (op.ldp == 64 && pf && big) launch_quad<64, true, Q_TILE_BYTES_BIG>(op, X, out, ldo, nc, cvec, mode, s);
+    else if (op.ldp == 64 && pf) launch_quad<64, true, Q_TILE_BYTES>(op, X, out, ldo, nc, cvec, mode, s);
+    else if (op.ldp == 64 && big) launch_quad<64, false, Q_TILE_BYTES_BIG>(op, X, out, ldo, nc, cvec, mode, s);
+    else if (op.ldp == 64) launch_quad<64, false, Q_TILE_BYTES>(op, X, out, ldo, nc, cvec, mode, s);
+    else if (big) launch_quad<128, false, Q_TILE_BYTES_BIG>(op, X, out, ldo, nc, cvec, mode, s);
+    else launch_quad<128, false, Q_TILE_BYTES>(op, X, out, ldo, nc, cvec, mode, s);
   } else if (op.ldp == 64 && op.slots == 4) {
     if (pf) launch_tiled<64, 4, true>(op, X, out, ldo, nc, cvec, mode, s);
     else launch_tiled<64, 4, false>(op, X, out, ldo, nc, cvec, mode, s);

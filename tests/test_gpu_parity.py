@@ -493,6 +493,7 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     om = synth.gaussian_panel(n, k + p, 3).numpy()
     out = []
     routes = (None, "SAPCA_AT_UNPACK", "SAPCA_AT_NATURAL", "SAPCA_TILED_FROM_A")
+    monkeypatch.setenv("SAPCA_TILE_DEFAULT", "1")   # same LDS split on every route (a natural-order A^T could take the bigger tile)
     for route in routes:
         for r in routes[1:]:
             monkeypatch.delenv(r, raising=False)
