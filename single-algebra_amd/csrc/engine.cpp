@@ -110,6 +110,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   CsrView<T> At;
   const uint64_t* at_packed = nullptr;
+  bool at_seg_ready = false;
   {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
@@ -128,8 +129,14 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   {
     Scope sc(h, C_STATS);
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
-    if (at_packed) k::row_sums_packed(At.ptr, at_packed, n, d_stats, d_stats + n, s);
-    else k::row_sums(At, d_stats, d_stats + n, s);
+    if constexpr (sizeof(T) == 4) {
+      // packed tile-major rows: the statistics pass also leaves the A^T builder's per-row tile index behind
+      if (at_packed) {
+        k::at_stats_index(At.ptr, at_packed, n, m, tiled_ldp, h.tb_at, d_stats, d_stats + n, s);
+        at_seg_ready = true;
+      }
+    }
+    if (!at_seg_ready) k::row_sums(At, d_stats, d_stats + n, s);
     k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
     const double m_local = (double)m;
     SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &m_local, sizeof(double), hipMemcpyHostToDevice, s));
@@ -203,7 +210,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       Scope sc(h, C_PREPARE);
       const bool ok_a = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
       bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
-                            k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed));
+                            k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed, true,
+                                           at_seg_ready));
       if (at_packed && !ok_at) {   // someone needs the transposed CSR after all
         k::unpack_transposed(at_packed, nnz, const_cast<int32_t*>(At.idx), reinterpret_cast<float*>(const_cast<T*>(At.val)), s);
         at_packed = nullptr;

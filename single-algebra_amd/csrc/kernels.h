@@ -57,7 +57,12 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
 // rows_tile_major: S's rows were produced by transpose_csr(..., tile_major_nct = tiled_tile_count(S.cols, ldp))
 bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
                  bool rows_tile_major = false, const uint64_t* packed_rows = nullptr,   // packed_rows: S.idx / S.val are not
-                 bool allow_big_tile = true);                                            // filled, read (row << 32 | value) instead
+                 bool allow_big_tile = true,                                             // filled, read (row << 32 | value) instead
+                 bool seg_ready = false);   // buf.seg already holds the per-row tile index (at_stats_index)
+// Column statistics of A (row sums / sums of squares of the packed tile-major A^T rows, same summation order as
+// row_sums) and, in the same pass, the per-row tile index build_tiled(..., rows_tile_major, packed, ., seg_ready) needs.
+void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, int64_t cols, int ldp, TiledBuffers& buf,
+                    double* sum, double* sumsq, hipStream_t s);
 // number of interleaved column tiles the format uses for an operator with `cols` columns
 int tiled_tile_count(int64_t cols, int ldp);
 void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,

@@ -647,6 +647,53 @@ __global__ void tile_index_mod_kernel(const int64_t* __restrict__ ptr, const int
   }
 }
 
+// One pass over the packed tile-major rows: the column statistics of A (row sums of A^T, accumulated in
+// exactly the order of prep.hip's row_sums kernels) and seg[r][t] from the places where the tile changes.
+__global__ void at_stats_index_kernel(const int64_t* __restrict__ ptr, const uint64_t* __restrict__ packed, int64_t rows,
+                                      int nct, float inv_nct, double* __restrict__ sum, double* __restrict__ sumsq,
+                                      int32_t* __restrict__ seg) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    int32_t* sg = seg + r * (nct + 1);
+    double a = 0, b = 0;
+    int carry = -1;   // tile of the entry before this batch
+    for (int64_t eb = e0; eb < e1; eb += WAVE) {
+      const int64_t e = eb + lane;
+      const bool valid = e < e1;
+      int t = nct;   // past the end: closes every remaining boundary
+      if (valid) {
+        const uint64_t pv = packed[e];
+        const double v = (double)__uint_as_float((uint32_t)pv);
+        a += v;
+        b += v * v;
+        int q;
+        divmod_small((int)(pv >> 32), nct, inv_nct, q, t);
+      }
+      int tprev = __shfl_up(t, 1);
+      if (lane == 0) tprev = carry;
+      // entry e is the first one of tiles (tprev, t]; lanes past the end write the closing boundaries once
+      if (valid || e == e1)
+        for (int tt = tprev + 1; tt <= t; ++tt) sg[tt] = (int32_t)(e - e0);
+      carry = __shfl(t, WAVE - 1);
+    }
+    // rows whose length is a multiple of 64 (or zero) have not closed their boundaries yet
+    if (((e1 - e0) & (WAVE - 1)) == 0)
+      for (int tt = carry + 1 + lane; tt <= nct; tt += WAVE) sg[tt] = (int32_t)(e1 - e0);
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off);
+      b += __shfl_xor(b, off);
+    }
+    if (lane == 0) {
+      sum[r] = a;
+      if (sumsq) sumsq[r] = b;
+    }
+  }
+}
+
 // Streaming fill: a workgroup owns a quad; every (quad, tile) segment is four contiguous source runs
 // interleaved step by step ([k][g]) and padded with zero entries, written as one contiguous piece.
 __global__ void __launch_bounds__(256)
@@ -1071,7 +1118,7 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 
 // ---------------------------------------------------------------------------------- host side
 bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                 bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile) {
+                 bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready) {
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
   op = TiledOp();
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
@@ -1124,7 +1171,9 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   int32_t* d_seg = nullptr;
   if (!transposed) {
     d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nct + 1));
-    if (quad && rows_tile_major) {
+    if (quad && rows_tile_major && seg_ready) {
+      // at_stats_index() filled it in the statistics pass
+    } else if (quad && rows_tile_major) {
       hipLaunchKernelGGL(tile_index_mod_kernel, dim3(grid_for(S.rows * (int64_t)(nct + 1), 256, 16384)), dim3(256), 0, s,
                          S.ptr, S.idx, packed_rows, S.rows, nct, inv_nct, d_seg);
     } else if (quad) {
@@ -1196,7 +1245,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
               (long long)max_chunk, stage_cap, (long long)total);
     if (max_chunk <= stage_cap) break;
     if (tile_bytes == Q_TILE_BYTES_BIG)   // the estimate was too optimistic: take the default split instead of halving the row blocks
-      return build_tiled(S, transposed, ldp, op, buf, s, rows_tile_major, packed_rows, false);
+      return build_tiled(S, transposed, ldp, op, buf, s, rows_tile_major, packed_rows, false, seg_ready);
     if (attempt == 3 || nrb * 2 > op_rows) return false;  // does not fit: the caller stays on the row kernel
     nrb *= 2;
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
@@ -1242,6 +1291,16 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
+}
+
+void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, int64_t cols, int ldp, TiledBuffers& buf,
+                    double* sum, double* sumsq, hipStream_t s) {
+  if (rows == 0) return;
+  const int nct = tiled_tile_count(cols, ldp);
+  int32_t* d_seg = buf.seg.as<int32_t>((size_t)rows * (nct + 1));
+  hipLaunchKernelGGL(at_stats_index_kernel, dim3(grid_for(rows * WAVE, 256, 4096)), dim3(256), 0, s, ptr, packed, rows, nct,
+                     1.0f / (float)nct, sum, sumsq, d_seg);
+  SAPCA_HIP(hipGetLastError());
 }
 
 int tiled_tile_count(int64_t cols, int ldp) {
