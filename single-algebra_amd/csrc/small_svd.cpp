@@ -73,6 +73,144 @@ void jacobi_svd(const std::vector<double>& A, int l, std::vector<double>& U, std
   }
 }
 
+// ---- symmetric eigenproblem of the l x l Gram (f32 randomized path) ----------------------------------
+// Householder reduction to tridiagonal form (EISPACK tred2 structure): on return `a` holds the orthogonal
+// Q with A = Q T Q^T (row-major), d the diagonal and e the sub-diagonal of T (e[i] couples i-1 and i).
+static void householder_tridiag(double* a, int n, double* d, double* e) {
+  for (int i = n - 1; i >= 1; --i) {
+    const int l = i - 1;
+    double hh = 0, scale = 0;
+    double* ai = a + (size_t)i * n;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(ai[k]);
+      if (scale == 0.0) {
+        e[i] = ai[l];
+      } else {
+        for (int k = 0; k <= l; ++k) {
+          ai[k] /= scale;
+          hh += ai[k] * ai[k];
+        }
+        double f = ai[l];
+        double g = f >= 0 ? -std::sqrt(hh) : std::sqrt(hh);
+        e[i] = scale * g;
+        hh -= f * g;
+        ai[l] = f - g;
+        f = 0;
+        for (int j = 0; j <= l; ++j) {
+          double* aj = a + (size_t)j * n;
+          aj[i] = ai[j] / hh;
+          g = 0;
+          for (int k = 0; k <= j; ++k) g += aj[k] * ai[k];
+          for (int k = j + 1; k <= l; ++k) g += a[(size_t)k * n + j] * ai[k];
+          e[j] = g / hh;
+          f += e[j] * ai[j];
+        }
+        const double hk = f / (hh + hh);
+        for (int j = 0; j <= l; ++j) {
+          double* aj = a + (size_t)j * n;
+          f = ai[j];
+          e[j] = g = e[j] - hk * f;
+          for (int k = 0; k <= j; ++k) aj[k] -= f * e[k] + g * ai[k];
+        }
+      }
+    } else {
+      e[i] = ai[l];
+    }
+    d[i] = hh;
+  }
+  d[0] = 0;
+  e[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const int l = i - 1;
+    double* ai = a + (size_t)i * n;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0;
+        for (int k = 0; k <= l; ++k) g += ai[k] * a[(size_t)k * n + j];
+        for (int k = 0; k <= l; ++k) a[(size_t)k * n + j] -= g * a[(size_t)k * n + i];
+      }
+    }
+    d[i] = ai[i];
+    ai[i] = 1.0;
+    for (int j = 0; j <= l; ++j) a[(size_t)j * n + i] = ai[j] = 0.0;
+  }
+}
+
+// Implicit QL on (d, e) with the rotations applied to the ROWS of zt (zt = Q^T on entry: row i is the
+// i-th basis vector; on exit row i is the eigenvector of d[i]).  e[i] couples i-1 and i on entry.
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("arch=haswell", "default")))
+#endif
+static bool ql_implicit_rows(double* d, double* e, int n, double* zt) {
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 200) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          double* z0 = zt + (size_t)i * n;
+          double* z1 = zt + (size_t)(i + 1) * n;
+          for (int k = 0; k < n; ++k) {
+            const double fk = z1[k];
+            z1[k] = s * z0[k] + c * fk;
+            z0[k] = c * z0[k] - s * fk;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return true;
+}
+
+bool sym_eigh_desc(const std::vector<double>& A, int n, std::vector<double>& w, std::vector<double>& Vt) {
+  w.assign((size_t)std::max(n, 0), 0.0);
+  Vt.assign((size_t)n * n, 0.0);
+  if (n <= 0) return true;
+  std::vector<double> a(A.begin(), A.begin() + (size_t)n * n), d((size_t)n), e((size_t)n), zt((size_t)n * n);
+  householder_tridiag(a.data(), n, d.data(), e.data());
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < n; ++k) zt[(size_t)i * n + k] = a[(size_t)k * n + i];   // rows of zt = columns of Q
+  if (!ql_implicit_rows(d.data(), e.data(), n, zt.data())) return false;
+  std::vector<int> order((size_t)n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] > d[y]; });
+  for (int c = 0; c < n; ++c) {
+    w[c] = d[order[c]];
+    std::copy(zt.begin() + (size_t)order[c] * n, zt.begin() + (size_t)(order[c] + 1) * n, Vt.begin() + (size_t)c * n);
+  }
+  return true;
+}
+
 bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z) {
   // Implicit QL with Wilkinson shifts (EISPACK tql2 structure).  e[i] couples (i-1, i), e[0] unused.
   Z.assign((size_t)n * n, 0.0);

@@ -14,4 +14,10 @@ void jacobi_svd(const std::vector<double>& A, int l, std::vector<double>& U, std
 // n x n) the eigenvectors in columns.  Returns false if it failed to converge.
 bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z);
 
+// Eigen-decomposition of the symmetric row-major n x n matrix A (Householder tridiagonalisation + implicit
+// QL, eigenvectors accumulated in rows so that every rotation runs over contiguous memory).  On return w
+// holds the eigenvalues in DESCENDING order and row i of Vt the unit eigenvector of w[i].  Returns false
+// if QL failed to converge.
+bool sym_eigh_desc(const std::vector<double>& A, int n, std::vector<double>& w, std::vector<double>& Vt);
+
 }  // namespace sapca
