@@ -536,3 +536,26 @@ def test_staged_and_direct_format_fill_agree(monkeypatch):
     want = O.fit(A64.indptr.astype(np.int64), A64.indices.astype(np.int64), A64.data, m, n, n_components=k, n_oversamples=p,
                  n_power_iterations=q, omega=om)
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
+
+
+@pytest.mark.parametrize("m,n,dens,k,p", [(1027, 333, 0.1, 7, 5), (37, 1200, 0.2, 3, 4), (5, 70, 0.5, 2, 2), (2051, 65, 0.3, 9, 3)])
+def test_staged_sweep_on_ragged_shapes(m, n, dens, k, p):
+    """odd row counts (incomplete quads and blocks), more columns than rows, empty rows and columns, one-tile and
+    many-tile operators: the staged path forced on, against the oracle with the same Omega"""
+    rng = np.random.default_rng(m * 7 + n)
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, dens, seed=m + n, dtype=torch.float32))
+    A = mat(ptr, idx, val, m, n).tolil()
+    A[m // 2, :] = 0            # an empty row
+    A[:, n // 3] = 0            # an empty column
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    om = synth.gaussian_panel(n, k + p, 11).numpy()
+    A64 = A.astype(np.float64)
+    want = O.fit(A64.indptr.astype(np.int64), A64.indices.astype(np.int64), A64.data, m, n, n_components=k, n_oversamples=p,
+                 n_power_iterations=2, omega=om)
+    pca = _builder(k, p, 2).spmm_variant(2).build().set_omega(om)
+    t = pca.fit_transform(A)
+    np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=2e-4)
+    np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), O.explained_variance_ratio(want.explained_variance), atol=5e-5)
+    assert t.shape == (m, k) and np.isfinite(t).all()
