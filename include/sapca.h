@@ -218,6 +218,51 @@ sapca_status sapca_normalize_panel_f64(sapca_handle h, int32_t normalizer, uint6
 sapca_status sapca_generate_omega_f32(sapca_handle h, uint64_t rows, uint64_t l, float* out);
 sapca_status sapca_generate_omega_f64(sapca_handle h, uint64_t rows, uint64_t l, double* out);
 
+/* ---- device-resident workflow: upload once, preprocess and analyse in HBM ----
+ * The consumer's typical pipeline is normalize -> log1p -> PCA (/root/reference/src/lib.rs:28-33).
+ * sapca_upload_csr_* copies a host CsrMatrix (usize indices) into buffers owned by the handle and
+ * returns the device arrays (valid until the next host-matrix call on this handle or its
+ * destruction); the *_device_* entry points below and sapca_fit*_csr_device_* then work on them
+ * without touching PCIe again.                                                                  */
+sapca_status sapca_upload_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                  const uint64_t* row_offsets, const uint64_t* col_indices, const float* values,
+                                  const int64_t** d_row_offsets, const int32_t** d_col_indices, float** d_values);
+sapca_status sapca_upload_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                  const uint64_t* row_offsets, const uint64_t* col_indices, const double* values,
+                                  const int64_t** d_row_offsets, const int32_t** d_col_indices, double** d_values);
+/* <CsrMatrix<T> as Normalize<T>>::normalize::<f64>(&sums, target, &direction)
+ * (/root/reference/src/sparse/csr.rs:1012-1066): every stored value of row (direction 0) or
+ * column (direction 1) i becomes T(f64(value) * (target / sums[i])) where sums[i] > 0; others
+ * are left alone.  `sums` is a HOST array of length m (ROW) or n (COLUMN); a wrong length is
+ * SAPCA_ERR_ARG (the dense twin's message, src/dense/mod.rs; the CSR impl would index out of
+ * bounds).  `values` is the DEVICE value array, modified in place.                             */
+sapca_status sapca_normalize_csr_device_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                            const int64_t* row_offsets, const int32_t* col_indices, float* values,
+                                            const double* sums, uint64_t sums_len, double target, int32_t direction);
+sapca_status sapca_normalize_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                            const int64_t* row_offsets, const int32_t* col_indices, double* values,
+                                            const double* sums, uint64_t sums_len, double target, int32_t direction);
+/* <CsrMatrix<T> as Log1P<T>>::log1p_normalize (csr.rs:1069-1078): value = ln(1 + value) in T,
+ * in place on the DEVICE value array.                                                           */
+sapca_status sapca_log1p_csr_device_f32(sapca_handle h, uint64_t nnz, float* values);
+sapca_status sapca_log1p_csr_device_f64(sapca_handle h, uint64_t nnz, double* values);
+/* The per-row (direction 0) or per-column (direction 1) statistics of the MatrixSum /
+ * MatrixNonZero / MatrixMinMax traits in one call on a device-resident CSR: sum_row|col
+ * (csr.rs:259-392), sum_row|col_squared (:558-630), nonzero_row|col (:23-134, stored entries),
+ * min_max_row|col (:917-1008: over the stored entries; a row/column without any keeps
+ * (T::MAX, -T::MAX), the reference's initial values).  Outputs are HOST arrays of length m or n;
+ * any may be NULL.  Sums are accumulated in f64 (the reference accumulates in the caller's T, in
+ * storage order).  var_row|col (csr.rs:632-726) is host arithmetic on these:
+ *   var = (sumsq/N - (sum/N)^2) * N/(N-1), N = the other dimension.                             */
+sapca_status sapca_stats_csr_device_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                        const int64_t* row_offsets, const int32_t* col_indices, const float* values,
+                                        int32_t direction, double* sum, double* sum_squared, uint64_t* nonzero,
+                                        float* min_out, float* max_out);
+sapca_status sapca_stats_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                        const int64_t* row_offsets, const int32_t* col_indices, const double* values,
+                                        int32_t direction, double* sum, double* sum_squared, uint64_t* nonzero,
+                                        double* min_out, double* max_out);
+
 /* ---- multi-GPU: one process per GPU, rows range-partitioned ---------------- */
 /* nnz-balanced contiguous row ranges: bounds[0]=0 <= ... <= bounds[nparts]=m.  Pure host code. */
 sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint32_t nparts, uint64_t* bounds);

@@ -16,7 +16,8 @@ las2 for Lanczos).  It is cross-checked in tests/ against independent
 implementations (numpy exact SVD, sklearn.utils.extmath.randomized_svd /
 svd_flip, scipy.sparse.linalg.svds) and against the two data fixtures the
 reference's own tests hold for column sums (src/sparse/csc.rs:1071-1094,1123-1129;
-src/sparse/csr.rs:1385-1404).
+src/sparse/csr.rs:1385-1404).  The preprocessing / statistics functions at the end of this file ARE pinned by
+reference-held test data (tests/golden/ref_pins_preproc.npz).
 
 Every function cites the reference lines it restates (paths relative to
 /root/reference).
@@ -379,3 +380,59 @@ def subspace_angle(V1t, V2t):
     r = q2 - q1 @ (q1.T @ q2)
     s = np.linalg.svd(r, compute_uv=False)
     return float(np.arcsin(min(1.0, s.max())))
+
+# --------------------------------------------------------------------------
+# Preprocessing and the remaining CSR statistics.  PINNED by the reference's own test
+# data: src/sparse/csr.rs:1516-1552 (normalize), :1385-1422 (nonzero_col/row), src/sparse/csc.rs:1071-1226
+# (sum_row/col, min_max) -- tests/golden/ref_pins_preproc.npz.
+# --------------------------------------------------------------------------
+ROW, COLUMN = 0, 1
+
+
+def normalize_csr(indptr, indices, data, sums, target, direction):
+    """Normalize<T> for CsrMatrix, src/sparse/csr.rs:1012-1066 with U = f64: scale_i = target / sums_i where
+    sums_i > 0 else 0 (:1019-1029); value = T(U(value) * scale) where scale > 0 (:1037-1041, :1052-1059)."""
+    sums = np.asarray(sums, dtype=np.float64)
+    scale = np.where(sums > 0, float(target) / np.where(sums > 0, sums, 1.0), 0.0)
+    out = np.array(data, copy=True)
+    if int(direction) == COLUMN:
+        sc = scale[np.asarray(indices)]
+    else:
+        sc = np.repeat(scale, np.diff(np.asarray(indptr)))
+    hit = sc > 0
+    out[hit] = (out[hit].astype(np.float64) * sc[hit]).astype(out.dtype)
+    return out
+
+
+def log1p_csr(data):
+    """Log1P for CsrMatrix, src/sparse/csr.rs:1069-1078: value = (1 + value).ln() in T"""
+    data = np.asarray(data)
+    return np.log((data.dtype.type(1) + data).astype(data.dtype)).astype(data.dtype)
+
+
+def stats_csr(indptr, indices, data, m, n, direction):
+    """(sum, sum_squared, nonzero, min, max) per row or per column: sum_row/col (csr.rs:259-392),
+    sum_*_squared (:558-630), nonzero_row/col (:23-134: stored entries), min_max_row/col (:917-1008: over
+    the stored entries, empty rows/columns keep Item::max_value()/min_value() = (T::MAX, -T::MAX))."""
+    indptr, indices, data = np.asarray(indptr), np.asarray(indices), np.asarray(data)
+    ln = n if int(direction) == COLUMN else m
+    key = indices if int(direction) == COLUMN else np.repeat(np.arange(m), np.diff(indptr))
+    d64 = data.astype(np.float64)
+    sm = np.bincount(key, weights=d64, minlength=ln)
+    sq = np.bincount(key, weights=d64 * d64, minlength=ln)
+    nz = np.bincount(key, minlength=ln).astype(np.uint64)
+    big = np.finfo(data.dtype).max
+    lo = np.full(ln, big, dtype=data.dtype)
+    hi = np.full(ln, -big, dtype=data.dtype)
+    np.minimum.at(lo, key, data)
+    np.maximum.at(hi, key, data)
+    return sm, sq, nz, lo, hi
+
+
+def variance_from_sums(sm, sq, N):
+    """var_col / var_row, src/sparse/csr.rs:632-726: mean = sum/N; (sumsq/N - mean^2) * N/(N-1); 0 when N <= 1"""
+    N = float(N)
+    if N <= 1:
+        return np.zeros_like(np.asarray(sm, dtype=np.float64))
+    mean = np.asarray(sm, dtype=np.float64) / N
+    return (np.asarray(sq, dtype=np.float64) / N - mean ** 2) * (N / (N - 1.0))

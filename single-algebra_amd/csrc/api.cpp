@@ -196,6 +196,87 @@ sapca_status colstats_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
   });
 }
 
+// ---- device-resident workflow: upload once, preprocess and analyse in HBM -------------
+template <typename T>
+sapca_status upload_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci,
+                         const T* v, const int64_t** d_ptr, const int32_t** d_idx, T** d_val) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(d_ptr && d_idx && d_val, SAPCA_ERR_ARG, "null output pointer");
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    *d_ptr = A.ptr;
+    *d_idx = A.idx;
+    *d_val = const_cast<T*>(A.val);
+  });
+}
+
+template <typename T>
+sapca_status normalize_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, const int32_t* i, T* v,
+                              const double* sums, uint64_t sums_len, double target, int32_t direction) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(direction == 0 || direction == 1, SAPCA_ERR_ARG, "direction must be 0 (ROW) or 1 (COLUMN)");
+    const uint64_t want = direction == 1 ? n : m;
+    SAPCA_CHECK(sums != nullptr || want == 0, SAPCA_ERR_ARG, "null sums");
+    SAPCA_CHECK(sums_len == want, SAPCA_ERR_ARG,
+                direction == 1 ? "Length of sums must match number of columns" : "Length of sums must match number of rows");
+    CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
+    if (want == 0 || nnz == 0) return;
+    h->prep_key.valid = false;   // the values change under any cached preparation
+    double* d = h->stats.as<double>(2 * want);
+    SAPCA_HIP(hipMemcpyAsync(d, sums, want * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    sapca::k::normalize_csr(A, v, d, target, direction == 1, d + want, h->stream);
+    SAPCA_HIP(hipStreamSynchronize(h->stream));   // `sums` may go out of scope
+  });
+}
+
+template <typename T>
+sapca_status log1p_device(sapca_handle h, uint64_t nnz, T* v) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(v != nullptr || nnz == 0, SAPCA_ERR_ARG, "null values");
+    h->prep_key.valid = false;
+    sapca::k::log1p_values(v, (int64_t)nnz, h->stream);
+    SAPCA_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+// direction 0: per row (sum_row, sum_row_squared, nonzero_row, min_max_row); 1: per column (the same on A^T)
+template <typename T>
+sapca_status stats_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, const int32_t* i, const T* v,
+                          int32_t direction, double* sum, double* sumsq, uint64_t* nonzero, T* minv, T* maxv) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(direction == 0 || direction == 1, SAPCA_ERR_ARG, "direction must be 0 (ROW) or 1 (COLUMN)");
+    CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
+    hipStream_t s = h->stream;
+    const uint64_t len = direction == 1 ? n : m;
+    if (len == 0) return;
+    h->prep_key.valid = false;   // the statistics and transposition buffers are shared with prepare()
+    CsrView<T> R = A;
+    if (direction == 1) {
+      // (the transposition buffers are shared with prepare())
+      int64_t* at_ptr = h->at_ptr.as<int64_t>(n + 1);
+      int32_t* at_idx = h->at_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
+      T* at_val = h->at_val.as<T>(std::max<uint64_t>(nnz, 1));
+      sapca::k::transpose_csr(A, at_ptr, at_idx, at_val, h->scratch, s);
+      R.rows = (int64_t)n; R.cols = (int64_t)m; R.ptr = at_ptr; R.idx = at_idx; R.val = at_val;
+    }
+    double* d = h->stats.as<double>(3 * len + 1);
+    T* dmm = h->out_tmp.as<T>(2 * len);
+    sapca::k::row_stats(R, d, d + len, dmm, dmm + len, s);
+    sapca::k::row_lengths_f64(R.ptr, (int64_t)len, d + 2 * len, s);
+    std::vector<double> host(3 * len);
+    std::vector<T> mm(2 * len);
+    SAPCA_HIP(hipMemcpyAsync(host.data(), d, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(mm.data(), dmm, mm.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+    for (uint64_t j = 0; j < len; ++j) {
+      if (sum) sum[j] = host[j];
+      if (sumsq) sumsq[j] = host[len + j];
+      if (nonzero) nonzero[j] = (uint64_t)host[2 * len + j];
+      if (minv) minv[j] = mm[j];
+      if (maxv) maxv[j] = mm[len + j];
+    }
+  });
+}
+
 template <typename T>
 sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci,
                        const T* v, const T* mu, uint64_t l, const T* In, T* Out, bool transposed) {
@@ -434,6 +515,21 @@ sapca_status sapca_set_omega_f64(sapca_handle h, const double* omega, size_t row
   sapca_status sapca_colstats_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,        \
                                         const uint64_t* ci, const T* v, T* sc, T* ssq, uint64_t* cnt) {                  \
     return colstats_host<T>(h, m, n, nnz, ro, ci, v, sc, ssq, cnt);                                                      \
+  }                                                                                                                      \
+  sapca_status sapca_upload_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,          \
+                                      const uint64_t* ci, const T* v, const int64_t** dp, const int32_t** di, T** dv) {  \
+    return upload_host<T>(h, m, n, nnz, ro, ci, v, dp, di, dv);                                                          \
+  }                                                                                                                      \
+  sapca_status sapca_normalize_csr_device_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p,  \
+                                                const int32_t* i, T* v, const double* sums, uint64_t sums_len,            \
+                                                double target, int32_t direction) {                                      \
+    return normalize_device<T>(h, m, n, nnz, p, i, v, sums, sums_len, target, direction);                                \
+  }                                                                                                                      \
+  sapca_status sapca_log1p_csr_device_##SUF(sapca_handle h, uint64_t nnz, T* v) { return log1p_device<T>(h, nnz, v); }    \
+  sapca_status sapca_stats_csr_device_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p,      \
+                                            const int32_t* i, const T* v, int32_t direction, double* sum, double* sumsq, \
+                                            uint64_t* nonzero, T* minv, T* maxv) {                                       \
+    return stats_device<T>(h, m, n, nnz, p, i, v, direction, sum, sumsq, nonzero, minv, maxv);                           \
   }                                                                                                                      \
   sapca_status sapca_spmm_csr_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,            \
                                     const uint64_t* ci, const T* v, const T* mu, uint64_t l, const T* X, T* Y) {         \

@@ -41,6 +41,19 @@ void column_counts_f64(const int32_t* idx, int64_t nnz, int64_t n, double* out, 
 template <typename T>
 void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* seg, hipStream_t s);
 
+// ---- preproc.hip (preprocessing and statistics on a device-resident CSR) ----------
+// Normalize<T> for CsrMatrix (csr.rs:1012-1066): values *= target / sums[row or column] where the sum is > 0.
+// d_sums: device, length rows or cols; d_scale: device scratch of the same length.
+template <typename T>
+void normalize_csr(const CsrView<T>& A, T* values, const double* d_sums, double target, bool by_column, double* d_scale,
+                   hipStream_t s);
+// Log1P (csr.rs:1069-1078): values = ln(1 + values), in T.
+template <typename T>
+void log1p_values(T* values, int64_t nnz, hipStream_t s);
+// sum_row, sum_row_squared, min_max_row of a CSR (applied to A^T: the column versions); any output may be null.
+template <typename T>
+void row_stats(const CsrView<T>& A, double* sum, double* sumsq, T* minv, T* maxv, hipStream_t s);
+
 // ---- spmm.hip --------------------------------------------------------------------------
 // Y[r][j] = sum_e val_e X[col_e][j] - cvec[j]   for j < ncols; X has leading dimension ldx
 // (multiple of 16/sizeof(T)... see spmm.hip), Y leading dimension ldy.  cvec may be null.

@@ -48,6 +48,7 @@ _TYPED = [
     "sapca_get_explained_variance_ratio", "sapca_get_cumulative_explained_variance_ratio",
     "sapca_get_feature_importances", "sapca_colstats_csr", "sapca_spmm_csr", "sapca_spmmt_csr",
     "sapca_normalize_panel", "sapca_generate_omega",
+    "sapca_upload_csr", "sapca_normalize_csr_device", "sapca_log1p_csr_device", "sapca_stats_csr_device",
 ]
 _PLAIN = [
     "sapca_options_default", "sapca_abi_version", "sapca_create", "sapca_destroy", "sapca_last_error",

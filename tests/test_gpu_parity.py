@@ -559,3 +559,88 @@ def test_staged_sweep_on_ragged_shapes(m, n, dens, k, p):
     np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=2e-4)
     np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), O.explained_variance_ratio(want.explained_variance), atol=5e-5)
     assert t.shape == (m, k) and np.isfinite(t).all()
+
+
+# ------------------------------------------------------------------ device-resident preprocessing and statistics
+def _resident(A, sess=None):
+    sess = sess or ops.Session()
+    A = A.tocsr()
+    A.sort_indices()
+    return sess, sess.upload(A.indptr, A.indices, A.data, A.shape[0], A.shape[1])
+
+
+def test_normalize_and_statistics_on_the_reference_test_vectors(golden):
+    """the data the reference's own tests hold (csr.rs:1385-1422, 1516-1552; csc.rs:1071-1226), through the C ABI"""
+    import scipy.sparse as sp
+    g = golden("ref_pins_preproc.npz")
+    A = sp.coo_matrix((g["norm_vals"], (g["norm_rows"], g["norm_cols"])), shape=(3, 3)).tocsr()
+    for direction, sums, want in ((ops.COLUMN, g["norm_col_sums"], g["norm_expected_col"]), (ops.ROW, g["norm_row_sums"], g["norm_expected_row"])):
+        for dt in (np.float64, np.float32):
+            sess, R = _resident(A.astype(dt))
+            got = R.normalize(sums, float(g["norm_target"]), direction).values()
+            assert np.abs(got - want).max() < (float(g["norm_tol"]) if dt == np.float64 else 1e-6)
+    sess, R = _resident(sp.csr_matrix(g["nz_dense"]))
+    np.testing.assert_array_equal(R.stats(ops.COLUMN)[2], g["nz_col"])
+    np.testing.assert_array_equal(R.stats(ops.ROW)[2], g["nz_row"])
+    sess, R = _resident(sp.csr_matrix(g["sum_dense"]))
+    sc, _, _, loc, hic = R.stats(ops.COLUMN)
+    sr, _, _, lor, hir = R.stats(ops.ROW)
+    np.testing.assert_array_equal(sc, g["sum_col"])
+    np.testing.assert_array_equal(sr, g["sum_row"])
+    assert loc[0] == g["min_col0"] and hic[0] == g["max_col0"] and lor[2] == g["min_row2"] and hir[2] == g["max_row2"]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_preprocessing_and_statistics_against_the_oracle(dt):
+    m, n = 3000, 700
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, 0.06, seed=12, dtype=torch.float32 if dt == np.float32 else torch.float64))
+    val = np.abs(val).astype(dt)                       # count-like: log1p of negative values is not the use case
+    A = mat(ptr, idx, val, m, n).tolil()
+    A[5, :] = 0
+    A[:, 9] = 0
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    ptr, idx, val = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data
+    sess, R = _resident(A)
+    for direction in (ops.ROW, ops.COLUMN):
+        want = O.stats_csr(ptr, idx, val, m, n, direction)
+        got = R.stats(direction)
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-12 if dt == np.float64 else 1e-6)
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-12 if dt == np.float64 else 1e-6)
+        np.testing.assert_array_equal(got[2], want[2])
+        np.testing.assert_array_equal(got[3], want[3])     # min / max: exact, including the (MAX, -MAX) of empty rows and columns
+        np.testing.assert_array_equal(got[4], want[4])
+        N = m if direction == ops.COLUMN else n
+        np.testing.assert_allclose(R.variance(direction), O.variance_from_sums(want[0], want[1], N), rtol=1e-9, atol=1e-12)
+    row_sums = R.stats(ops.ROW)[0]
+    got = R.normalize(row_sums, 1e4, ops.ROW).values()
+    want = O.normalize_csr(ptr, idx, val, row_sums, 1e4, ops.ROW)
+    np.testing.assert_array_equal(got, want)               # IEEE multiply in f64, one rounding: bit-exact
+    got2 = R.log1p().values()
+    np.testing.assert_allclose(got2, O.log1p_csr(want), rtol=3e-7 if dt == np.float32 else 1e-15)   # libm vs device log: <= 2 ulp
+    col_sums = R.stats(ops.COLUMN)[0]
+    got3 = R.normalize(col_sums, 1.0, ops.COLUMN).values()
+    np.testing.assert_array_equal(got3, O.normalize_csr(ptr, idx, got2, col_sums, 1.0, ops.COLUMN))
+    with pytest.raises(L.SapcaError, match="Length of sums") as e:
+        R.normalize(col_sums[:-1], 1.0, ops.COLUMN)
+    assert e.value.status == L.ERR_ARG
+
+
+def test_resident_workflow_normalize_log1p_pca():
+    """upload once -> normalize -> log1p -> fit_transform on the resident copy (src/lib.rs:28-33), against the
+    oracle run on the CPU-preprocessed matrix"""
+    m, n, k, p, q = 4000, 900, 8, 6, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.05, k, seed=21, dtype=torch.float32))
+    sess, R = _resident(mat(ptr, idx, val, m, n))
+    row_sums = R.stats(ops.ROW)[0]
+    R.normalize(row_sums, 1e3, ops.ROW).log1p()
+    v2 = O.log1p_csr(O.normalize_csr(ptr, idx, val, row_sums, 1e3, ops.ROW))
+    np.testing.assert_allclose(R.values(), v2, rtol=3e-7)
+    om = synth.gaussian_panel(n, k + p, 2).numpy()
+    pca = _builder(k, p, q).build().set_omega(om)
+    t = pca.fit_transform(R.as_device_csr()).cpu().numpy()
+    want = O.fit(ptr, idx, R.values().astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=1e-4)
+    assert O.subspace_angle(pca.components_(np.float64), want.components) < 1e-4
+    assert t.shape == (m, k)
