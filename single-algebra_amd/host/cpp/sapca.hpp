@@ -52,6 +52,59 @@ SAPCA_ABI(f32, float)
 SAPCA_ABI(f64, double)
 #undef SAPCA_ABI
 
+// Direction of the reference's Normalize / statistics traits (single-algebra src/utils.rs)
+enum class Direction : int32_t { ROW = 0, COLUMN = 1 };
+
+// A CsrMatrix uploaded once into buffers owned by a handle: Normalize / Log1P / MatrixSum / MatrixNonZero /
+// MatrixMinMax (src/sparse/csr.rs:23-134, 259-392, 558-630, 917-1078) run on the resident copy and the device
+// entry points of the estimators take the same arrays (src/lib.rs:28-33: normalize -> log1p -> PCA).
+template <typename T> struct ResidentAbi;
+#define SAPCA_RES(SUF, T)                                                                                          \
+  template <> struct ResidentAbi<T> {                                                                              \
+    static sapca_status upload(sapca_handle h, const CsrRef<T>& x, const int64_t** p, const int32_t** i, T** v) { return sapca_upload_csr_##SUF(h, x.nrows, x.ncols, x.nnz, x.row_offsets, x.col_indices, x.values, p, i, v); } \
+    static sapca_status normalize(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, const int32_t* i, T* v, const double* s, uint64_t sl, double t, int32_t d) { return sapca_normalize_csr_device_##SUF(h, m, n, nnz, p, i, v, s, sl, t, d); } \
+    static sapca_status log1p(sapca_handle h, uint64_t nnz, T* v) { return sapca_log1p_csr_device_##SUF(h, nnz, v); } \
+    static sapca_status stats(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, const int32_t* i, const T* v, int32_t d, double* s, double* q, uint64_t* c, T* lo, T* hi) { return sapca_stats_csr_device_##SUF(h, m, n, nnz, p, i, v, d, s, q, c, lo, hi); } \
+  };
+SAPCA_RES(f32, float)
+SAPCA_RES(f64, double)
+#undef SAPCA_RES
+
+template <typename T>
+class ResidentCsr {
+ public:
+  ResidentCsr(sapca_handle h, const CsrRef<T>& x) : h_(h), m_(x.nrows), n_(x.ncols), nnz_(x.nnz) {
+    check(ResidentAbi<T>::upload(h_, x, &ptr_, &idx_, &val_));
+  }
+  void normalize(const std::vector<double>& sums, double target, Direction d) {
+    check(ResidentAbi<T>::normalize(h_, m_, n_, nnz_, ptr_, idx_, val_, sums.data(), sums.size(), target, (int32_t)d));
+  }
+  void log1p_normalize() { check(ResidentAbi<T>::log1p(h_, nnz_, val_)); }
+  std::vector<double> sum(Direction d) const {
+    std::vector<double> s(d == Direction::COLUMN ? n_ : m_);
+    check(ResidentAbi<T>::stats(h_, m_, n_, nnz_, ptr_, idx_, val_, (int32_t)d, s.data(), nullptr, nullptr, nullptr, nullptr));
+    return s;
+  }
+  std::vector<uint64_t> nonzero(Direction d) const {
+    std::vector<uint64_t> c(d == Direction::COLUMN ? n_ : m_);
+    check(ResidentAbi<T>::stats(h_, m_, n_, nnz_, ptr_, idx_, val_, (int32_t)d, nullptr, nullptr, c.data(), nullptr, nullptr));
+    return c;
+  }
+  const int64_t* row_offsets() const { return ptr_; }
+  const int32_t* col_indices() const { return idx_; }
+  T* values() const { return val_; }
+
+ private:
+  void check(sapca_status st) const {
+    if (st != SAPCA_OK) throw Error(st, sapca_last_error(h_));
+  }
+  sapca_handle h_;
+  uint64_t m_, n_, nnz_;
+  const int64_t* ptr_ = nullptr;
+  const int32_t* idx_ = nullptr;
+  T* val_ = nullptr;
+};
+
 template <typename T>
 class SparsePCA {
  public:

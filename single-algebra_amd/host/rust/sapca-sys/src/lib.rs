@@ -83,4 +83,31 @@ extern "C" {
     pub fn sapca_get_cumulative_explained_variance_ratio_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
     pub fn sapca_get_feature_importances_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
     pub fn sapca_get_feature_importances_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
+
+    // device-resident workflow: upload once, then Normalize / Log1P / MatrixSum / MatrixNonZero / MatrixMinMax and
+    // the fits on the resident copy (src/lib.rs:28-33 of single-algebra: normalize -> log1p -> PCA)
+    pub fn sapca_upload_csr_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64, col_indices: *const u64,
+                                values: *const f32, d_row_offsets: *mut *const i64, d_col_indices: *mut *const i32,
+                                d_values: *mut *mut f32) -> c_int;
+    pub fn sapca_upload_csr_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const u64, col_indices: *const u64,
+                                values: *const f64, d_row_offsets: *mut *const i64, d_col_indices: *mut *const i32,
+                                d_values: *mut *mut f64) -> c_int;
+    pub fn sapca_normalize_csr_device_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
+                                          col_indices: *const i32, values: *mut f32, sums: *const f64, sums_len: u64,
+                                          target: f64, direction: i32) -> c_int;
+    pub fn sapca_normalize_csr_device_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
+                                          col_indices: *const i32, values: *mut f64, sums: *const f64, sums_len: u64,
+                                          target: f64, direction: i32) -> c_int;
+    pub fn sapca_log1p_csr_device_f32(h: sapca_handle, nnz: u64, values: *mut f32) -> c_int;
+    pub fn sapca_log1p_csr_device_f64(h: sapca_handle, nnz: u64, values: *mut f64) -> c_int;
+    pub fn sapca_stats_csr_device_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
+                                      col_indices: *const i32, values: *const f32, direction: i32, sum: *mut f64,
+                                      sum_squared: *mut f64, nonzero: *mut u64, min_out: *mut f32, max_out: *mut f32) -> c_int;
+    pub fn sapca_stats_csr_device_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
+                                      col_indices: *const i32, values: *const f64, direction: i32, sum: *mut f64,
+                                      sum_squared: *mut f64, nonzero: *mut u64, min_out: *mut f64, max_out: *mut f64) -> c_int;
+    pub fn sapca_fit_transform_csr_device_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
+                                              col_indices: *const i32, values: *const f32, out: *mut f32) -> c_int;
+    pub fn sapca_fit_transform_csr_device_f64(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
+                                              col_indices: *const i32, values: *const f64, out: *mut f64) -> c_int;
 }

@@ -64,3 +64,21 @@ def test_partition_rows_balances_nnz():
     assert ops.partition_rows(np.zeros(5, np.int64), 2).tolist() == [0, 2, 4]
     b = ops.partition_rows(np.array([0, 3, 6]), 4).astype(np.int64)
     assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
+
+
+def test_cpp_mirror_compiles(tmp_path):
+    """the header-only C++ mirror of the reference interface (estimators + resident workflow) against include/sapca.h"""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        import pytest
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "m.cpp"
+    src.write_text('#include "%s"\n'
+                   'template class sapca::ResidentCsr<float>;\ntemplate class sapca::ResidentCsr<double>;\n'
+                   'int main() { auto b = sapca::SparsePCABuilder<float>().n_components(2); (void)b; return 0; }\n'
+                   % os.path.join(root, "single-algebra_amd", "host", "cpp", "sapca.hpp"))
+    r = subprocess.run([cxx, "-std=c++17", "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
