@@ -35,14 +35,21 @@ spmv_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, co
   const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
   for (int64_t r = wave; r < rows; r += nwaves) {
     const int64_t e0 = ptr[r], e1 = ptr[r + 1];
-    double a0 = 0, a1 = 0;
+    // four independent (value, index, gather) chains per lane: the loop is bound by memory latency, not bytes
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int64_t e = e0 + lane;
-    for (; e + WAVE < e1; e += 2 * WAVE) {
-      a0 = fma((double)val[e], x[idx[e]], a0);
-      a1 = fma((double)val[e + WAVE], x[idx[e + WAVE]], a1);
+    for (; e + 3 * WAVE < e1; e += 4 * WAVE) {
+      const int c0 = __builtin_nontemporal_load(idx + e), c1 = __builtin_nontemporal_load(idx + e + WAVE);
+      const int c2 = __builtin_nontemporal_load(idx + e + 2 * WAVE), c3 = __builtin_nontemporal_load(idx + e + 3 * WAVE);
+      const T v0 = __builtin_nontemporal_load(val + e), v1 = __builtin_nontemporal_load(val + e + WAVE);
+      const T v2 = __builtin_nontemporal_load(val + e + 2 * WAVE), v3 = __builtin_nontemporal_load(val + e + 3 * WAVE);
+      a0 = fma((double)v0, x[c0], a0);
+      a1 = fma((double)v1, x[c1], a1);
+      a2 = fma((double)v2, x[c2], a2);
+      a3 = fma((double)v3, x[c3], a3);
     }
-    if (e < e1) a0 = fma((double)val[e], x[idx[e]], a0);
-    a0 += a1;
+    for (; e < e1; e += WAVE) a0 = fma((double)val[e], x[idx[e]], a0);
+    a0 = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) a0 += __shfl_xor(a0, off);
     if (lane == 0) y[r] = a0;
