@@ -46,8 +46,6 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
   SAPCA_CHECK(n < (1ull << 31) && m < (1ull << 31), SAPCA_ERR_ARG, "more than 2^31-1 rows or columns is not supported");
   hipStream_t s = h->stream;
   h->prep_key.valid = false;  // the upload buffers are about to hold a different matrix
-  const int ev = h->timer.enabled ? -1 : -1;
-  (void)ev;
   auto t0 = std::chrono::steady_clock::now();
   int64_t* d_ptr = h->in_ptr.as<int64_t>(m + 1);
   int32_t* d_idx = h->in_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));

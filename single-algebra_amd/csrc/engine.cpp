@@ -560,8 +560,6 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     const T* mu = h.mean_used_dev.ptr<T>();
     const T* comps = h.components_dev.ptr<T>();
     T* W = h.panel_w.as<T>((size_t)n_used * ldk);
-    const bool vec_ok = true;
-    (void)vec_ok;
     if (ref_sem && !masked) {
       // Q2 (sparse/mod.rs:268-282): t_ik = sum_j cnt_j (x_ij - [center] mu_j) V_kj
       k::scaled_transpose(comps, n_used, k, d_cnt, W, ldk, s);

@@ -17,7 +17,6 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
                    const uint64_t** packed_rows_out = nullptr);   // with tile_major_nct: leave the rows packed as
                                                                    // (row << 32 | value bits) in `scratch`, skip t_idx / t_val
 void unpack_transposed(const uint64_t* packed, int64_t nnz, int32_t* t_idx, float* t_val, hipStream_t s);
-void row_sums_packed(const int64_t* ptr, const uint64_t* packed, int64_t rows, double* sum, double* sumsq, hipStream_t s);
 // Row sums of a CSR (applied to A^T: the reference's sum_col / sum_col_squared), f64 accumulation.
 template <typename T>
 void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s);

@@ -159,32 +159,6 @@ __global__ void row_sums_kernel(const int64_t* __restrict__ ptr, const T* __rest
   }
 }
 
-// the same over the sort's packed output (row << 32 | value bits): same order, same sums
-__global__ void row_sums_packed_kernel(const int64_t* __restrict__ ptr, const uint64_t* __restrict__ packed, int64_t rows,
-                                double* __restrict__ sum, double* __restrict__ sumsq) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
-  for (int64_t r = wave; r < rows; r += nwaves) {
-    double a = 0, b = 0;
-    const int64_t e1 = ptr[r + 1];
-    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) {
-      const double v = (double)__uint_as_float((uint32_t)packed[e]);
-      a += v;
-      b += v * v;
-    }
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-      a += __shfl_xor(a, off);
-      b += __shfl_xor(b, off);
-    }
-    if (lane == 0) {
-      sum[r] = a;
-      if (sumsq) sumsq[r] = b;
-    }
-  }
-}
-
 template <typename T>
 __global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
                                   const int32_t* __restrict__ o2m, int64_t* __restrict__ cnt) {
@@ -431,13 +405,6 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
 void unpack_transposed(const uint64_t* packed, int64_t nnz, int32_t* t_idx, float* t_val, hipStream_t s) {
   if (nnz == 0) return;
   hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, packed, nnz, t_idx, t_val);
-  SAPCA_HIP(hipGetLastError());
-}
-
-void row_sums_packed(const int64_t* ptr, const uint64_t* packed, int64_t rows, double* sum, double* sumsq, hipStream_t s) {
-  if (rows == 0) return;
-  hipLaunchKernelGGL(row_sums_packed_kernel, dim3(grid_for(rows * WAVE, 256, 4096)), dim3(256), 0, s, ptr, packed, rows, sum,
-                     sumsq);
   SAPCA_HIP(hipGetLastError());
 }
 
