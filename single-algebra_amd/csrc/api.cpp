@@ -1,6 +1,8 @@
 // extern "C" surface of libsapca.so (include/sapca.h).  Every function: set device, try,
 // translate exceptions into a status + per-handle message.  No compute lives here.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -37,7 +39,41 @@ sapca_status guarded(sapca_handle h, F&& f) {
   }
 }
 
-// Host CSR (nalgebra layout, usize indices) -> device CSR in the handle's upload buffers.
+// Host CSR (nalgebra layout, usize indices) -> device CSR in the handle's upload buffers (SURVEY.md §8f-1).
+// PCIe is the bound of this path, so the usize column indices are narrowed to int32 on the HOST, chunk by
+// chunk into a page-locked ring by a few threads, while the previous chunk's DMA (and, first, the values')
+// is in flight: 8 bytes per stored entry cross the bus instead of 12.
+namespace {
+constexpr size_t kUpChunk = (size_t)16 << 20;   // indices per chunk (64 MiB of int32)
+
+// out[i] = (int32) in[i]; returns true if any in[i] >= n
+bool narrow_chunk(const uint64_t* in, int32_t* out, size_t count, uint64_t n, unsigned nthreads) {
+  std::atomic<bool> bad{false};
+  auto work = [&](size_t lo, size_t hi) {
+    bool b = false;
+    for (size_t i = lo; i < hi; ++i) {
+      const uint64_t c = in[i];
+      b |= c >= n;
+      out[i] = (int32_t)c;
+    }
+    if (b) bad.store(true, std::memory_order_relaxed);
+  };
+  if (nthreads <= 1 || count < (size_t)1 << 16) {
+    work(0, count);
+  } else {
+    std::vector<std::thread> th;
+    const size_t per = (count + nthreads - 1) / nthreads;
+    for (unsigned t = 1; t < nthreads; ++t) {
+      const size_t lo = std::min(count, t * per), hi = std::min(count, lo + per);
+      if (lo < hi) th.emplace_back(work, lo, hi);
+    }
+    work(0, std::min(count, per));
+    for (auto& x : th) x.join();
+  }
+  return bad.load();
+}
+}  // namespace
+
 template <typename T>
 CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* row_offsets,
                   const uint64_t* col_indices, const T* values) {
@@ -50,19 +86,43 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
   int64_t* d_ptr = h->in_ptr.as<int64_t>(m + 1);
   int32_t* d_idx = h->in_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
   T* d_val = h->in_val.as<T>(std::max<uint64_t>(nnz, 1));
-  uint64_t* d64 = h->up64.as<uint64_t>(m + 1 + nnz + 8);
-  int* flag = reinterpret_cast<int*>(d64 + m + 1 + nnz);
+  uint64_t* d64 = h->up64.as<uint64_t>(m + 1 + 8);
+  int* flag = reinterpret_cast<int*>(d64 + m + 1);
   SAPCA_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
   SAPCA_HIP(hipMemcpyAsync(d64, row_offsets, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  static const bool on_device = getenv("SAPCA_UPLOAD_NARROW_ON_DEVICE") != nullptr;   // the first version: ship u64, narrow on the GPU
+  bool bad_host = false;
+  if (nnz == 0 || !on_device) sapca::k::narrow_indices(d64, d64, (int64_t)m, 0, (int64_t)n, d_ptr, d_idx, flag, s);   // row offsets only
   if (nnz) {
-    SAPCA_HIP(hipMemcpyAsync(d64 + m + 1, col_indices, nnz * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     SAPCA_HIP(hipMemcpyAsync(d_val, values, nnz * sizeof(T), hipMemcpyHostToDevice, s));
+    if (on_device) {
+      uint64_t* d64i = h->up64i.as<uint64_t>(nnz);
+      SAPCA_HIP(hipMemcpyAsync(d64i, col_indices, nnz * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+      sapca::k::narrow_indices(d64, d64i, (int64_t)m, (int64_t)nnz, (int64_t)n, d_ptr, d_idx, flag, s);
+    } else {
+      const unsigned nthreads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+      const size_t chunk = std::min<size_t>(kUpChunk, nnz);
+      for (int b = 0; b < 2; ++b) {
+        h->up_stage[b].ensure(chunk * sizeof(int32_t));
+        if (!h->up_done[b]) SAPCA_HIP(hipEventCreateWithFlags(&h->up_done[b], hipEventDisableTiming));
+      }
+      bool used[2] = {false, false};
+      int b = 0;
+      for (size_t off = 0; off < nnz; off += chunk, b ^= 1) {
+        const size_t cnt = std::min<size_t>(chunk, nnz - off);
+        if (used[b]) SAPCA_HIP(hipEventSynchronize(h->up_done[b]));   // its DMA has drained
+        int32_t* stage = static_cast<int32_t*>(h->up_stage[b].p);
+        bad_host |= narrow_chunk(col_indices + off, stage, cnt, n, nthreads);
+        SAPCA_HIP(hipMemcpyAsync(d_idx + off, stage, cnt * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        SAPCA_HIP(hipEventRecord(h->up_done[b], s));
+        used[b] = true;
+      }
+    }
   }
-  sapca::k::narrow_indices(d64, d64 + m + 1, (int64_t)m, (int64_t)nnz, (int64_t)n, d_ptr, d_idx, flag, s);
   int bad = 0;
   SAPCA_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
   SAPCA_HIP(hipStreamSynchronize(s));
-  SAPCA_CHECK(bad == 0, SAPCA_ERR_ARG, "column index out of range");
+  SAPCA_CHECK(bad == 0 && !bad_host, SAPCA_ERR_ARG, "column index out of range");
   h->timings.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   CsrView<T> v;
   v.rows = (int64_t)m; v.cols = (int64_t)n; v.nnz = (int64_t)nnz;
@@ -433,6 +493,8 @@ void sapca_destroy(sapca_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->comm.destroy();
+  for (int b = 0; b < 2; ++b)
+    if (h->up_done[b]) (void)hipEventDestroy(h->up_done[b]);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

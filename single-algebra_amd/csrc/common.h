@@ -73,6 +73,32 @@ struct CsrView {
 };
 
 // Tile-major companion of an f32 CSR operator for the LDS-staged sweep (spmm_tiled.hip).
+// Page-locked host staging buffer (grow-only), for the chunked upload of the host entry points.
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void* ensure(size_t bytes) {
+    if (bytes > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+      cap = 0;
+      hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        p = nullptr;
+        throw Error(SAPCA_ERR_NOMEM, std::string("hipHostMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+      }
+      cap = bytes;
+    }
+    return p;
+  }
+};
+
 struct TiledOp {
   bool valid = false;
   int64_t rows = 0, cols = 0, total_entries = 0;

@@ -51,7 +51,9 @@ struct sapca_handle_s {
   double prep_total_var = 0;
 
   // device buffers (grow-only)
-  sapca::DevBuf in_ptr, in_idx, in_val, up64, out_tmp;           // host-entry uploads
+  sapca::DevBuf in_ptr, in_idx, in_val, up64, up64i, out_tmp;    // host-entry uploads
+  sapca::PinnedBuf up_stage[2];                                   // page-locked ring of the chunked index upload
+  hipEvent_t up_done[2] = {nullptr, nullptr};
   sapca::DevBuf at_ptr, at_idx, at_val;                          // A^T
   sapca::DevBuf ca_ptr, ca_idx, ca_val, cat_ptr, cat_idx, cat_val;  // mask-compacted A, A^T
   sapca::DevBuf shifted_val;                                     // a_ij - mu_j (quirk Q3 operand)
