@@ -109,14 +109,15 @@ struct TiledOp {
   int slots = 2;            // lane groups per wave the entry stream was padded for
   int fmt = 0;              // 0: two half-waves share a row; 1: "quad", one row per 16-lane group
   int tile_bytes = 0;       // LDS bytes of one panel tile (the entry staging takes the rest of the 160 KiB)
-  const int32_t* blk_row0 = nullptr;   // [nrb+1]
+  const int32_t* blk_row0 = nullptr;   // [nrb+1] slot positions
+  const uint32_t* row_perm = nullptr;  // [rows] slot position -> row (rows sorted by length, longest first); null = identity
   const int64_t* chunk_off = nullptr;  // [nrb*nct+1] entry offsets
   const uint32_t* wave_off = nullptr;  // [nrb*nct][8]
   const uint8_t* steps = nullptr;      // [nrb*nct][256]
   const void* ent = nullptr;           // {u32 lds byte offset, f32 value}
 };
 struct TiledBuffers {
-  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank;
+  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens;
 };
 
 struct Stream {

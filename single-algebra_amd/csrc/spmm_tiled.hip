@@ -420,8 +420,8 @@ tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 // one block per (row block, column tile): steps of every quad (= its longest row segment), entry
 // offset of every wave, chunk size
 __global__ void __launch_bounds__(BLOCK_ROWS)
-quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct,
-                  uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
+quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm,
+                  int nct, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
                   int64_t* __restrict__ chunk_size) {
   __shared__ uint32_t scan[BLOCK_ROWS];
   const int rb = blockIdx.x / nct, ct = blockIdx.x % nct;
@@ -430,7 +430,7 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
   const int lr = threadIdx.x;   // local row; its quad is lr / 4
   int len = 0;
   if (lr < nrows) {
-    const int64_t r = row0 + lr;
+    const int64_t r = perm ? (int64_t)perm[row0 + lr] : (int64_t)row0 + lr;   // slot -> row (rows sorted by length)
     len = seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
   }
   int qmax = max(len, __shfl_xor(len, 1));
@@ -458,20 +458,22 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
 // (k*4 + g) of its quad's segment in that tile's chunk (g = row mod 4 within the block)
 __global__ void __launch_bounds__(256)
 quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
-                 int64_t rows, const int32_t* __restrict__ blk_row0, int nrb, int nct, float inv_nct, int ldp_bytes,
-                 const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off, Ent* __restrict__ ent) {
+                 int64_t rows, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nrb, int nct,
+                 float inv_nct, int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
+                 Ent* __restrict__ ent) {
   extern __shared__ uint32_t cnt_all[];   // per wave and tile: slot of the row's next entry (relative to the block's first chunk)
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   uint32_t* cnt = cnt_all + (size_t)wave * nct;
-  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-  if (r >= rows) return;
-  int lo = 0, hi = nrb;   // row block: the last b with blk_row0[b] <= r
+  const int64_t sp = (int64_t)blockIdx.x * 4 + wave;   // slot position; its row is perm[sp]
+  if (sp >= rows) return;
+  const int64_t r = perm ? (int64_t)perm[sp] : sp;
+  int lo = 0, hi = nrb;   // row block: the last b with blk_row0[b] <= sp
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if ((int64_t)blk_row0[mid] <= r) lo = mid; else hi = mid;
+    if ((int64_t)blk_row0[mid] <= sp) lo = mid; else hi = mid;
   }
   const int rb = lo;
-  const int lr = (int)(r - blk_row0[rb]);
+  const int lr = (int)(sp - blk_row0[rb]);
   const int qd = lr >> 2;
   const uint32_t g = (uint32_t)(lr & 3);
   const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
@@ -516,7 +518,8 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 constexpr int QF_CAP = 4096;   // entries of one quad staged in LDS (32 KiB)
 __global__ void __launch_bounds__(256)
 quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
-                        const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
+                        const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
+                        const uint32_t* __restrict__ perm, int nct, float inv_nct,
                         int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
                         Ent* __restrict__ ent) {
   extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
@@ -528,14 +531,17 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   if (4 * qd >= nrows) return;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const int qrows = min(4, nrows - 4 * qd);
-  const int64_t r0 = (int64_t)row0 + 4 * qd;
+  const int64_t s0 = (int64_t)row0 + 4 * qd;   // first slot position of the quad
+  int64_t rowof[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rowof[g] = g < qrows ? (perm ? (int64_t)perm[s0 + g] : s0 + g) : 0;
   const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
   const uint32_t* __restrict__ qoff = quad_off + ((int64_t)rb * Q_BLOCK_QUADS + qd) * nct;
   // segment sizes (4 x the longest of the quad's rows in the tile), then their exclusive scan
   for (int t = threadIdx.x; t < nct; t += 256) {
     int mx = 0;
     for (int g = 0; g < qrows; ++g) {
-      const int32_t* sg = seg + (r0 + g) * (nct + 1);
+      const int32_t* sg = seg + rowof[g] * (nct + 1);
       mx = max(mx, sg[t + 1] - sg[t]);
     }
     lofs[t + 1] = (uint32_t)mx * 4u;
@@ -567,7 +573,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   } else {
     // direct route: zero the padding slots of this wave's row in global memory
     if (wave < qrows) {
-      const int32_t* sg = seg + (r0 + wave) * (nct + 1);
+      const int32_t* sg = seg + rowof[wave] * (nct + 1);
       for (int t = lane; t < nct; t += WAVE) {
         const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
         Ent* dst = ent + coff[t] + qoff[t];
@@ -583,7 +589,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   }
   __syncthreads();
   if (wave < qrows) {
-    const int64_t r = r0 + wave;
+    const int64_t r = rowof[wave];
     const int64_t e0 = ptr[r], e1 = ptr[r + 1];
     uint32_t* cnt = cnt_all + (size_t)wave * nct;
     // batches of 64 entries in column order; within a batch the LDS atomic hands out the ranks of
@@ -694,27 +700,57 @@ __global__ void at_stats_index_kernel(const int64_t* __restrict__ ptr, const uin
   }
 }
 
+// rows sorted by length: keys for the descending sort and the identity payload
+__global__ void row_len_iota_kernel(const int64_t* __restrict__ ptr, int64_t rows, uint32_t* __restrict__ len,
+                                    uint32_t* __restrict__ iota) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) {
+    len[r] = (uint32_t)(ptr[r + 1] - ptr[r]);
+    iota[r] = (uint32_t)r;
+  }
+}
+
+// sum over consecutive groups of four rows of 4 * (longest of the four): what the quads would hold if the
+// rows kept their natural order (the quad padding estimate that decides whether sorting is worth its cost)
+__global__ void __launch_bounds__(256)
+natural_quad_slots_kernel(const int64_t* __restrict__ ptr, int64_t rows, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[4];
+  unsigned long long acc = 0;
+  const int64_t nq = (rows + 3) / 4;
+  for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nq; qd += (int64_t)gridDim.x * blockDim.x) {
+    int64_t mx = 0;
+    for (int g = 0; g < 4 && 4 * qd + g < rows; ++g) mx = max(mx, ptr[4 * qd + g + 1] - ptr[4 * qd + g]);
+    acc += (unsigned long long)(4 * mx);
+  }
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 // Streaming fill: a workgroup owns a quad; every (quad, tile) segment is four contiguous source runs
 // interleaved step by step ([k][g]) and padded with zero entries, written as one contiguous piece.
 __global__ void __launch_bounds__(256)
 quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
-                      const uint64_t* __restrict__ packed, const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, int nct, float inv_nct,
-                      int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
-                      Ent* __restrict__ ent) {
+                      const uint64_t* __restrict__ packed, const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
+                      const uint32_t* __restrict__ perm, int nct, float inv_nct, int ldp_bytes,
+                      const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off, Ent* __restrict__ ent) {
   extern __shared__ int32_t sg_lds[];   // [4][nct + 1] the quad's rows of seg
   const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   if (4 * qd >= nrows) return;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const int qrows = min(4, nrows - 4 * qd);
-  const int64_t r0 = (int64_t)row0 + 4 * qd;
+  const int64_t s0q = (int64_t)row0 + 4 * qd;   // first slot position of the quad; slot -> row through perm
   for (int i = threadIdx.x; i < 4 * (nct + 1); i += 256) {
     const int g = i / (nct + 1);
-    sg_lds[i] = g < qrows ? seg[(r0 + g) * (nct + 1) + (i - g * (nct + 1))] : 0;
+    const int64_t rg = g < qrows ? (perm ? (int64_t)perm[s0q + g] : s0q + g) : 0;
+    sg_lds[i] = g < qrows ? seg[rg * (nct + 1) + (i - g * (nct + 1))] : 0;
   }
   __syncthreads();
   const int g = lane & 3, k0 = lane >> 2;   // lane -> (step k0 + 16*pass, row g)
-  const int64_t base = g < qrows ? ptr[r0 + g] : 0;
+  const int64_t base = g < qrows ? ptr[perm ? (int64_t)perm[s0q + g] : s0q + g] : 0;
   const int32_t* mysg = sg_lds + g * (nct + 1);
   const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
   const uint32_t* __restrict__ qoff = quad_off + ((int64_t)rb * Q_BLOCK_QUADS + qd) * nct;
@@ -979,7 +1015,8 @@ __device__ __forceinline__ void load_tile_interleaved(v4f (&r)[N], const float* 
 
 template <int LDP, bool PREFETCH, int TILE_B>
 __global__ void __launch_bounds__(QTHREADS)
-spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const int64_t* __restrict__ chunk_off,
+spmm_quad_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct, int tc,
+                 const int64_t* __restrict__ chunk_off,
                  const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, const Ent* __restrict__ ent,
                  int64_t panel_rows, const float* __restrict__ X, int nsplit, int tiles_per_split,
                  float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec,
@@ -1067,7 +1104,8 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const in
     for (int j = 0; j < RG; ++j) {
       const int r = 4 * j + g;
       if (r < my_rows) {
-        float* y = dst_base + (int64_t)(row0 + 4 * quad0 + r) * ldo + col;
+        const int64_t sp = (int64_t)row0 + 4 * quad0 + r;   // slot position -> output row
+        float* y = dst_base + (perm ? (int64_t)perm[sp] : sp) * ldo + col;
         if (col + 3 < ncols) {
           v4f o = acc[j][v];
           o.x -= cv[0]; o.y -= cv[1]; o.z -= cv[2]; o.w -= cv[3];
@@ -1094,7 +1132,7 @@ void launch_quad(const TiledOp& op, const float* X, float* out, int ldo, int nco
     attr = true;
   }
   hipLaunchKernelGGL((spmm_quad_kernel<LDP, PREFETCH, TILE_B>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
-                     op.blk_row0, op.nct, op.tc, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
+                     op.blk_row0, op.row_perm, op.nct, op.tc, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
                      reinterpret_cast<const Ent*>(op.ent), op.cols, X, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
                      ncols, cvec, mode);
 }
@@ -1183,6 +1221,38 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
       build_tile_index(S, tc, nct, d_seg, s);
     }
   }
+  // Rows sorted by length, longest first (quad format built from a CSR): the four rows of a quad and the
+  // quads of a wave then have similar lengths in every (interleaved) tile, which is what keeps the quad
+  // padding and the per-tile barrier wait small on matrices with skewed row lengths (cell depth, gene
+  // detection rate).  Blocks are cut from the sorted order with about equal entry counts (at most 512 rows).
+  uint32_t* d_perm = nullptr;
+  std::vector<uint32_t> sorted_len;
+  bool sort_rows = quad && !transposed && getenv("SAPCA_NO_ROWSORT") == nullptr;
+  if (sort_rows && getenv("SAPCA_ROWSORT_ALWAYS") == nullptr) {
+    // homogeneous rows pad little in their natural order: skip the sort (0.2 ms per operator at C2) unless the
+    // natural quads would hold 10 % more slots than entries
+    unsigned long long* d_slots = reinterpret_cast<unsigned long long*>(buf.misc.as<int64_t>(8)) + 4;
+    SAPCA_HIP(hipMemsetAsync(d_slots, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(natural_quad_slots_kernel, dim3(grid_for((S.rows + 3) / 4, 256, 1024)), dim3(256), 0, s, S.ptr, S.rows, d_slots);
+    unsigned long long slots_nat = 0;
+    SAPCA_HIP(hipMemcpyAsync(&slots_nat, d_slots, sizeof(slots_nat), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+    sort_rows = (double)slots_nat > 1.10 * (double)S.nnz;
+  }
+  if (sort_rows) {
+    uint32_t* d_len = buf.lens.as<uint32_t>((size_t)2 * S.rows);
+    uint32_t* d_len_sorted = d_len + S.rows;
+    uint32_t* d_iota = buf.perm.as<uint32_t>((size_t)2 * S.rows);
+    d_perm = d_iota + S.rows;
+    hipLaunchKernelGGL(row_len_iota_kernel, dim3(grid_for(S.rows, 256, 1 << 30)), dim3(256), 0, s, S.ptr, S.rows, d_len, d_iota);
+    size_t sb = 0;
+    SAPCA_HIP(rocprim::radix_sort_pairs_desc(nullptr, sb, d_len, d_len_sorted, d_iota, d_perm, (size_t)S.rows, 0u, 32u, s));
+    char* tmp = static_cast<char*>(buf.tmp.ensure(sb + 256));
+    SAPCA_HIP(rocprim::radix_sort_pairs_desc(tmp, sb, d_len, d_len_sorted, d_iota, d_perm, (size_t)S.rows, 0u, 32u, s));
+    sorted_len.resize((size_t)S.rows);
+    SAPCA_HIP(hipMemcpyAsync(sorted_len.data(), d_len_sorted, sorted_len.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+  }
   // The entries of one (row block, tile) must fit the LDS staging.  Skewed inputs (a dense cluster
   // inside one tile) can exceed it: halve the rows per block and recount, a few times at most.
   int tiles_per_split = 0;
@@ -1196,8 +1266,27 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   for (int attempt = 0;; ++attempt) {
     tiles_per_split = (nct + nsplit - 1) / nsplit;
     nsplit = (nct + tiles_per_split - 1) / tiles_per_split;
-    std::vector<int32_t> blk((size_t)nrb + 1);
-    for (int64_t b = 0; b <= nrb; ++b) blk[(size_t)b] = (int32_t)(op_rows * b / nrb);
+    std::vector<int32_t> blk;
+    if (sort_rows) {
+      // greedy cut of the sorted rows: close a block at block_rows rows or at the per-block entry budget
+      const double budget = (double)S.nnz / (double)nrb;
+      blk.push_back(0);
+      double acc = 0;
+      int in_block = 0;
+      for (int64_t r = 0; r < op_rows; ++r) {
+        acc += sorted_len[(size_t)r];
+        ++in_block;
+        const bool last = r + 1 == op_rows;
+        if (last || in_block == block_rows || acc >= budget * (double)blk.size()) {
+          blk.push_back((int32_t)(r + 1));
+          in_block = 0;
+        }
+      }
+      nrb = (int64_t)blk.size() - 1;
+    } else {
+      blk.resize((size_t)nrb + 1);
+      for (int64_t b = 0; b <= nrb; ++b) blk[(size_t)b] = (int32_t)(op_rows * b / nrb);
+    }
     nchunks = nrb * nct;
     d_blk = buf.blk.as<int32_t>((size_t)nrb + 1);
     d_steps = buf.steps.as<uint8_t>((size_t)nchunks * BLOCK_ROWS);
@@ -1214,7 +1303,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                          (size_t)2 * BLOCK_ROWS * maskw * sizeof(uint32_t), s, S.ptr, S.idx, d_seg, S.rows, d_blk, (int)nrb, nct,
                          maskw, d_rank, reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     } else if (quad)
-      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     else if (slots == 2)
       hipLaunchKernelGGL((tiled_count_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
@@ -1270,15 +1359,15 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (runs_fill)
     hipLaunchKernelGGL(quad_fill_runs_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
-                       (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, nct, inv_nct,
-                       ldp * 4, d_chunk, d_quad_off, d_ent);
+                       (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, d_perm, nct,
+                       inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (staged_fill)
     hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)QF_CAP * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
-                       nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+                       d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (quad)
     hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
-                       S.ptr, S.idx, S.val, S.rows, d_blk, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+                       S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (slots == 2)
     hipLaunchKernelGGL((tiled_fill_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, S.ptr, S.idx, S.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
@@ -1288,7 +1377,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   SAPCA_HIP(hipGetLastError());
   op.rows = op_rows; op.cols = op_cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
-  op.blk_row0 = d_blk; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
+  op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
 }

@@ -494,6 +494,7 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     out = []
     routes = (None, "SAPCA_AT_UNPACK", "SAPCA_AT_NATURAL", "SAPCA_TILED_FROM_A")
     monkeypatch.setenv("SAPCA_TILE_DEFAULT", "1")   # same LDS split on every route (a natural-order A^T could take the bigger tile)
+    monkeypatch.setenv("SAPCA_NO_ROWSORT", "1")     # and the same row order: the builder straight from A does not sort rows by length
     for route in routes:
         for r in routes[1:]:
             monkeypatch.delenv(r, raising=False)
@@ -644,3 +645,37 @@ def test_resident_workflow_normalize_log1p_pca():
     np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=1e-4)
     assert O.subspace_angle(pca.components_(np.float64), want.components) < 1e-4
     assert t.shape == (m, k)
+
+
+def test_rows_sorted_by_length_on_a_skewed_matrix(monkeypatch):
+    """log-normal row lengths and power-law column popularity (cell depth, gene detection rate): the staged formats
+    sort rows by length and cut blocks by entry count; forced on and off, against the oracle"""
+    m, n, k, p, q = 5000, 800, 8, 6, 2
+    rng = np.random.default_rng(3)
+    depth = np.exp(0.9 * rng.standard_normal(m))
+    pop = (np.arange(1, n + 1) ** -0.8)[rng.permutation(n)]
+    P = np.minimum(1.0, depth[:, None] * pop[None, :] * (0.06 * m * n / (depth.sum() * pop.sum())))
+    D = (rng.random((m, n)) < P) * rng.uniform(1.0, 5.0, (m, n))
+    import scipy.sparse as sp
+    A = sp.csr_matrix(D.astype(np.float32))
+    A.sort_indices()
+    lens = np.diff(A.indptr)
+    assert lens.max() > 8 * np.median(lens)          # really skewed
+    om = synth.gaussian_panel(n, k + p, 5).numpy()
+    A64 = A.astype(np.float64)
+    want = O.fit(A64.indptr.astype(np.int64), A64.indices.astype(np.int64), A64.data, m, n, n_components=k, n_oversamples=p,
+                 n_power_iterations=q, omega=om)
+    outs = []
+    for env in ("SAPCA_ROWSORT_ALWAYS", "SAPCA_NO_ROWSORT", None):
+        monkeypatch.delenv("SAPCA_ROWSORT_ALWAYS", raising=False)
+        monkeypatch.delenv("SAPCA_NO_ROWSORT", raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(A)
+        np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=1e-4)
+        assert O.subspace_angle(pca.components_(np.float64), want.components) < 1e-4
+        outs.append((pca.singular_values_(np.float64), t))
+    for o in outs[1:]:
+        np.testing.assert_allclose(o[0], outs[0][0], rtol=1e-6)
+        np.testing.assert_allclose(o[1], outs[0][1], atol=1e-4 * np.abs(outs[0][1]).max())
