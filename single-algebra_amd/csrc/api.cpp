@@ -495,6 +495,12 @@ void sapca_destroy(sapca_handle h) {
   h->comm.destroy();
   for (int b = 0; b < 2; ++b)
     if (h->up_done[b]) (void)hipEventDestroy(h->up_done[b]);
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

@@ -124,6 +124,25 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
   }
 
+  // A's format does not depend on the transposition: build it on a side stream while the sort runs on the
+  // main one (both are memory-latency bound and overlap well); the main stream joins before the first sweep.
+  bool a_built_aside = false, ok_a_aside = false;
+  if constexpr (sizeof(T) == 4) {
+    if (tiled_ldp != 0 && !masked && getenv("SAPCA_PREPARE_SERIAL") == nullptr) {
+      if (!h.stream2) {
+        SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
+      }
+      SAPCA_HIP(hipEventRecord(h.ev_fork, s));               // A is ready on the main stream at this point...
+      SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
+      h.tiled_a = TiledOp();
+      ok_a_aside = k::build_tiled(A, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+      SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));       // ...and the main stream waits for it at the end of prepare()
+      a_built_aside = true;
+    }
+  }
+
   // R1/R2 (csr.rs:259-312, 558-608) as row sums of A^T, plus the per-column stored-entry count.
   std::vector<double> sums((size_t)2 * n + 1, 0.0);
   {
@@ -203,12 +222,12 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   }
 
   // tile-major companions for the LDS-staged sweep
-  h.tiled_a = TiledOp();
+  if (!a_built_aside) h.tiled_a = TiledOp();
   h.tiled_at = TiledOp();
   if constexpr (sizeof(T) == 4) {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
-      const bool ok_a = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
+      const bool ok_a = a_built_aside ? ok_a_aside : k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
       bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
                             k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed, true,
                                            at_seg_ready));
@@ -224,6 +243,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }
     }
   }
+
+  if (a_built_aside) SAPCA_HIP(hipStreamWaitEvent(s, h.ev_join, 0));
 
   h.prep_key.ptr = A.ptr; h.prep_key.idx = A.idx; h.prep_key.val = A.val;
   h.prep_key.m = (uint64_t)m; h.prep_key.n = (uint64_t)n; h.prep_key.nnz = (uint64_t)nnz;

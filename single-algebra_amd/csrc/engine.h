@@ -13,6 +13,8 @@ struct sapca_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream2 = nullptr;        // side stream: A's format is built beside the transposition (prepare)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   // builder state
   std::vector<uint8_t> mask;
