@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <cstdlib>
+
 #include "lanczos.h"
 #include "small_svd.h"
 
@@ -53,6 +55,104 @@ spmv_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, co
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) a0 += __shfl_xor(a0, off);
     if (lane == 0) y[r] = a0;
+  }
+}
+
+// The same with x staged in LDS (operators with up to ~19k columns: the masked C3 matrix has 18k): the
+// per-entry gather then costs an LDS read instead of an L2 sector, which is what bounds the kernel above.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val, int64_t rows,
+                 int64_t cols, const double* __restrict__ x, double* __restrict__ y) {
+  extern __shared__ double xs[];
+  for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) xs[i] = x[i];
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int64_t e = e0 + lane;
+    for (; e + 3 * WAVE < e1; e += 4 * WAVE) {
+      const int c0 = __builtin_nontemporal_load(idx + e), c1 = __builtin_nontemporal_load(idx + e + WAVE);
+      const int c2 = __builtin_nontemporal_load(idx + e + 2 * WAVE), c3 = __builtin_nontemporal_load(idx + e + 3 * WAVE);
+      const T v0 = __builtin_nontemporal_load(val + e), v1 = __builtin_nontemporal_load(val + e + WAVE);
+      const T v2 = __builtin_nontemporal_load(val + e + 2 * WAVE), v3 = __builtin_nontemporal_load(val + e + 3 * WAVE);
+      a0 = fma((double)v0, xs[c0], a0);
+      a1 = fma((double)v1, xs[c1], a1);
+      a2 = fma((double)v2, xs[c2], a2);
+      a3 = fma((double)v3, xs[c3], a3);
+    }
+    for (; e < e1; e += WAVE) a0 = fma((double)val[e], xs[idx[e]], a0);
+    a0 = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) a0 += __shfl_xor(a0, off);
+    if (lane == 0) y[r] = a0;
+  }
+}
+
+// Long x (A^T y: x has one element per sample): x is cut into slices that fit LDS and a workgroup walks its
+// rows (rpw per wave) slice by slice.  The column indices of a CSR row ascend, so the entries of a slice are a
+// contiguous run; the run limits of all (row, slice) pairs of a wave are found up front, one binary search per
+// lane, and handed out with shuffles.
+constexpr int SLICE_WAVES = 16, SLICE_MAX_RPW = 8;
+template <typename T>
+__global__ void __launch_bounds__(SLICE_WAVES * WAVE)
+spmv_sliced_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val, int64_t rows,
+                   int64_t cols, int slice, int nslices, int rpw, const double* __restrict__ x, double* __restrict__ y) {
+  extern __shared__ double xs[];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  const int64_t r0 = ((int64_t)blockIdx.x * SLICE_WAVES + wave) * rpw;
+  // lane (j, t): first entry of row r0 + j whose column is >= t * slice   (t = 0..nslices; rpw * (nslices+1) <= 64)
+  int64_t bnd = 0;
+  {
+    const int j = lane / (nslices + 1), t = lane % (nslices + 1);
+    if (j < rpw && r0 + j < rows) {
+      int64_t lo = ptr[r0 + j], hi = ptr[r0 + j + 1];
+      const int64_t key = (int64_t)t * slice;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)idx[mid] < key) lo = mid + 1; else hi = mid;
+      }
+      bnd = lo;
+    }
+  }
+  double acc[SLICE_MAX_RPW];
+#pragma unroll
+  for (int j = 0; j < SLICE_MAX_RPW; ++j) acc[j] = 0;
+  for (int t = 0; t < nslices; ++t) {
+    const int64_t c0 = (int64_t)t * slice, c1 = min(cols, c0 + (int64_t)slice);
+    __syncthreads();   // the previous slice's readers are done
+    for (int64_t i = threadIdx.x; i < c1 - c0; i += blockDim.x) xs[i] = x[c0 + i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SLICE_MAX_RPW; ++j) {
+      if (j < rpw) {
+        const int64_t e0 = __shfl(bnd, j * (nslices + 1) + t), e1 = __shfl(bnd, j * (nslices + 1) + t + 1);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int64_t e = e0 + lane;
+        for (; e + 3 * WAVE < e1; e += 4 * WAVE) {
+          const int k0 = __builtin_nontemporal_load(idx + e), k1 = __builtin_nontemporal_load(idx + e + WAVE);
+          const int k2 = __builtin_nontemporal_load(idx + e + 2 * WAVE), k3 = __builtin_nontemporal_load(idx + e + 3 * WAVE);
+          const T v0 = __builtin_nontemporal_load(val + e), v1 = __builtin_nontemporal_load(val + e + WAVE);
+          const T v2 = __builtin_nontemporal_load(val + e + 2 * WAVE), v3 = __builtin_nontemporal_load(val + e + 3 * WAVE);
+          a0 = fma((double)v0, xs[k0 - c0], a0);
+          a1 = fma((double)v1, xs[k1 - c0], a1);
+          a2 = fma((double)v2, xs[k2 - c0], a2);
+          a3 = fma((double)v3, xs[k3 - c0], a3);
+        }
+        for (; e < e1; e += WAVE) a0 = fma((double)val[e], xs[idx[e] - c0], a0);
+        acc[j] += (a0 + a1) + (a2 + a3);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SLICE_MAX_RPW; ++j) {
+    double a = acc[j];
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0 && j < rpw && r0 + j < rows) y[r0 + j] = a;
   }
 }
 
@@ -157,6 +257,39 @@ inline unsigned grid1(int64_t n, int block = 256, int64_t cap = 1 << 30) {
 template <typename T>
 void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s) {
   if (A.rows == 0) return;
+  const size_t xbytes = (size_t)A.cols * sizeof(double);
+  static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
+  if (!no_lds && xbytes <= 150 * 1024 && A.rows >= 4096) {
+    static bool attr[2] = {false, false};
+    if (!attr[sizeof(T) == 8]) {
+      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024));
+      attr[sizeof(T) == 8] = true;
+    }
+    hipLaunchKernelGGL((spmv_ldsx_kernel<T>), dim3(256), dim3(1024), xbytes, s, A.ptr, A.idx, A.val, A.rows, A.cols, x, y);
+    return;
+  }
+  if (!no_lds && A.nnz >= 256 * A.rows && A.rows >= 1024) {   // long rows: slices of x through LDS
+    const int max_slice = 150 * 1024 / (int)sizeof(double);
+    const int nslices = (int)((A.cols + max_slice - 1) / max_slice);
+    const int slice = (int)((A.cols + nslices - 1) / nslices);
+    // one round of workgroups (256 CUs x 16 waves) when the wave's run-limit table fits its 64 lanes
+    int rpw = (int)((A.rows + 256 * SLICE_WAVES - 1) / (256 * SLICE_WAVES));
+    if (rpw < 1) rpw = 1;
+    if (rpw <= SLICE_MAX_RPW && rpw * (nslices + 1) <= WAVE) {
+      static bool attr2[2] = {false, false};
+      if (!attr2[sizeof(T) == 8]) {
+        SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sliced_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr2[sizeof(T) == 8] = true;
+      }
+      const int rows_per_block = SLICE_WAVES * rpw;
+      hipLaunchKernelGGL((spmv_sliced_kernel<T>), dim3((unsigned)((A.rows + rows_per_block - 1) / rows_per_block)),
+                         dim3(SLICE_WAVES * WAVE), (size_t)slice * sizeof(double), s, A.ptr, A.idx, A.val, A.rows, A.cols, slice,
+                         nslices, rpw, x, y);
+      return;
+    }
+  }
   hipLaunchKernelGGL((spmv_kernel<T>), dim3(grid1(A.rows * WAVE, 256, 8192)), dim3(256), 0, s, A.ptr, A.idx, A.val,
                      A.rows, x, y);
 }
