@@ -122,6 +122,34 @@ __global__ void pack_rows_permuted_kernel(const int64_t* __restrict__ ptr, const
   }
 }
 
+// f64 matrices: the sort carries a 16-byte (row, value) payload instead of a permutation that a random gather
+// has to resolve afterwards (6.6 ms of an 9.3 ms transposition at C3)
+struct alignas(16) RowVal64 {
+  uint32_t row;
+  uint32_t pad;
+  double val;
+};
+__global__ void pack_rows64_kernel(const int64_t* __restrict__ ptr, const double* __restrict__ val, int64_t rows,
+                                   RowVal64* __restrict__ packed) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) packed[e] = RowVal64{(uint32_t)r, 0u, val[e]};
+  }
+}
+__global__ void unpack_rows64_kernel(const RowVal64* __restrict__ packed, int64_t count, int32_t* __restrict__ t_idx,
+                                     double* __restrict__ t_val) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    const RowVal64 p = packed[i];
+    t_idx[i] = (int32_t)p.row;
+    t_val[i] = p.val;
+  }
+}
+
 __global__ void unpack_rows_kernel(const uint64_t* __restrict__ packed, int64_t count, int32_t* __restrict__ t_idx,
                                    float* __restrict__ t_val) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,6 +409,30 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
     }
     SAPCA_HIP(hipGetLastError());
     return;
+  }
+  if constexpr (sizeof(T) == 8) {
+    static const bool gather_route = getenv("SAPCA_TRANSPOSE_GATHER") != nullptr;
+    if (!gather_route) {
+      size_t sb = 0;
+      SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const RowVal64*)nullptr,
+                                          (RowVal64*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
+      const size_t a4 = (size_t)round_up(nnz * 4, 256), a16 = (size_t)round_up(nnz * 16, 256);
+      char* base = static_cast<char*>(scratch.ensure(a4 + 2 * a16 + sb + 256));
+      uint32_t* keys_out = reinterpret_cast<uint32_t*>(base);
+      RowVal64* packed = reinterpret_cast<RowVal64*>(base + a4);
+      RowVal64* packed_out = reinterpret_cast<RowVal64*>(base + a4 + a16);
+      void* tmp = base + a4 + 2 * a16;
+      hipLaunchKernelGGL(pack_rows64_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr,
+                         reinterpret_cast<const double*>(A.val), A.rows, packed);
+      SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, reinterpret_cast<const uint32_t*>(A.idx), keys_out, packed, packed_out,
+                                          (size_t)nnz, 0u, (unsigned)bits, s));
+      hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out,
+                         nnz, A.cols, t_ptr);
+      hipLaunchKernelGGL(unpack_rows64_kernel, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, packed_out, nnz, t_idx,
+                         reinterpret_cast<double*>(t_val));
+      SAPCA_HIP(hipGetLastError());
+      return;
+    }
   }
   size_t sort_bytes = 0;
   rocprim::counting_iterator<uint32_t> iota(0);
