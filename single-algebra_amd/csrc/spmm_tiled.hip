@@ -515,16 +515,16 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 // 8-byte store per entry, which is what it spends its time on.  Quads larger than the LDS image
 // (very long rows) take the direct route and zero their padding themselves, so the entry buffer
 // needs no memset on this path.
-constexpr int QF_CAP = 4096;   // entries of one quad staged in LDS (32 KiB)
+constexpr int QF_CAP_MIN = 4096, QF_CAP_MAX = 6144;   // entries of one quad staged in LDS: 32 KiB (more workgroups per CU) .. 48 KiB
 __global__ void __launch_bounds__(256)
 quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                         const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
-                        const uint32_t* __restrict__ perm, int nct, float inv_nct,
+                        const uint32_t* __restrict__ perm, int nct, int cap, float inv_nct,
                         int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
                         Ent* __restrict__ ent) {
   extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
-  Ent* stage = reinterpret_cast<Ent*>(qf_lds);     // [QF_CAP]
-  uint32_t* lofs = qf_lds + 2 * QF_CAP;            // [nct + 1] start of every tile's segment in the image
+  Ent* stage = reinterpret_cast<Ent*>(qf_lds);     // [cap]
+  uint32_t* lofs = qf_lds + 2 * cap;               // [nct + 1] start of every tile's segment in the image
   uint32_t* cnt_all = lofs + nct + 1;              // [4][nct] entries of row g seen so far in tile t
   const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
@@ -566,7 +566,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   }
   __syncthreads();
   const uint32_t total = lofs[nct];
-  const bool staged = total <= (uint32_t)QF_CAP;
+  const bool staged = total <= (uint32_t)cap;
   if (staged) {
     uint64_t* z = reinterpret_cast<uint64_t*>(stage);
     for (uint32_t i = threadIdx.x; i < total; i += 256) z[i] = 0;
@@ -1343,7 +1343,8 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
   const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
-                           (double)total <= 0.85 * QF_CAP * ((double)op_rows / 4.0) && nct <= 768;
+                           (double)total <= 0.85 * QF_CAP_MAX * ((double)op_rows / 4.0) && nct <= 768;
+  const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : QF_CAP_MAX;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= 4000;
   if (packed_rows && !runs_fill) return false;
   if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(Ent), s));
@@ -1363,8 +1364,8 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                        inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (staged_fill)
     hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
-                       (size_t)QF_CAP * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
-                       d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+                       (size_t)qf_cap * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
+                       d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (quad)
     hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
