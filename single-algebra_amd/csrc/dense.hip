@@ -186,96 +186,207 @@ chol_inv_kernel(const double* __restrict__ G, int l, int ld, double* __restrict_
   if (tid == 0 && bad) atomicAdd(info, bad);
 }
 
-// The same factorisation for l <= 64 on ONE wave: lane i owns row i of L (left-looking:
-// L[i][j] = (G[i][j] - sum_{k<j} L[i][k] L[j][k]) / L[j][j]) and afterwards column i of L^-1 by forward
-// substitution.  Everything lives in LDS, column-major and unpadded (the lane-strided operand is then
-// conflict-free and the other one a broadcast); there is no workgroup barrier on the critical path,
-// and the loops stay rolled (a fully unrolled register version is no faster: ~80 KB of straight-line
-// code fetched once).  Measured 85 us for l = 60: ~28 us of per-step skeleton (shuffle, sqrt, divide),
-// ~27 us for each triangular phase's dot products at one wave's issue rate.
-__global__ void __launch_bounds__(64)
-chol_inv_wave_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
-                     int* __restrict__ info) {
-  constexpr int N = 64;
-  extern __shared__ double cw_lds[];
-  double* Lc = cw_lds;             // Lc[k*N + i] = L[i][k]
-  double* Xc = cw_lds + N * N;     // Xc[k*N + i] = (L^-1)[k][i]
-  double* dinvs = Xc + N * N;
-  const int i = threadIdx.x;
-  for (int k = 0; k < l; ++k) Lc[k * N + i] = (i < l && k <= i) ? G[(size_t)i * ld + k] : 0.0;
-  double dg = i < l ? fabs(G[(size_t)i * ld + i]) : 0.0;
+// The same factorisation for l <= 64 on one workgroup of four waves, blocked.  The matrix sits in LDS
+// (row-major, pitch 65) padded to a multiple of 16 with a harmless diagonal.  Per 16-column block:
+// wave 0 takes the block's columns into registers, lane = matrix row, and runs the right-looking
+// elimination on them -- the pivot and the multipliers come from the lanes of the diagonal block through
+// v_readlane, so the diagonal factorisation and the triangular solve of the rows below are the same 16
+// unrolled steps (1/sqrt by Goldschmidt from v_rsq_f64: the divide would double the dependent chain) --
+// while wave 1 inverts the previous diagonal block in registers; then the four waves apply the rank-16
+// update to the trailing lower triangle as 16 x 16 block products on the matrix cores.
+// L^-1, block row by block row:  X_ij = -X_ii (sum_k L_ik X_kj), one wave per block; the inner sum leaves
+// the accumulator in exactly the lane layout the second product wants as its B operand.
+// 24 us for l = 60 (tools/ubench/chol_phases.hip: 32k of the 54k cycles are the 64 pivots at ~80 instructions
+// each, one wave's issue rate); a one-wave left-looking version with everything in LDS took 85 us.
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// s = sqrt(x), r = 1/sqrt(x) for a positive normal x
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& r) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+  }
+  g = fma(fma(-g, g, x), h, g);
+  s = g;
+  r = h + h;
+}
+
+// acc += A B for 16 x 16 blocks in LDS: A[i][k] = pa[i * sai + k * sak], B[k][j] = pb[k * sbk + j * sbj]
+__device__ __forceinline__ d4 block_mma(const double* pa, int sai, int sak, const double* pb, int sbk, int sbj, d4 acc,
+                                        int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  double a[4], b[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    a[ks] = pa[i * sai + (4 * ks + g) * sak];
+    b[ks] = pb[(4 * ks + g) * sbk + i * sbj];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) acc = mfma_f64(a[ks], b[ks], acc);
+  return acc;
+}
+
+constexpr int CHB = 16, CHN = 64, CHP = 65;
+constexpr int kCholBlockedLds = (2 * CHN * CHP + CHN) * (int)sizeof(double);
+#ifdef SAPCA_CHOL_TIMING   // tools/ubench/chol_phases.hip: shader-clock stamps at the phase boundaries
+__device__ unsigned long long sapca_chol_stamps[32];
+#define CHOL_STAMP(k) if (threadIdx.x == 0) sapca_chol_stamps[k] = __builtin_readcyclecounter();
+#else
+#define CHOL_STAMP(k)
+#endif
+
+// lanes 0..15 of the calling wave: row r of the diagonal block at c0 in, column r of its inverse out
+__device__ __forceinline__ void invert_diag_block(const double* Lm, double* Xm, const double* dinvs, int c0, int lane) {
+  const int r = lane & (CHB - 1);
+  double a[CHB], x[CHB];
+#pragma unroll
+  for (int k = 0; k < CHB; ++k) a[k] = Lm[(c0 + r) * CHP + c0 + k];
+  const double dmine = dinvs[c0 + r];
+#pragma unroll
+  for (int i = 0; i < CHB; ++i) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k + 1 < i; k += 2) {
+      s0 += readlane_f64(a[k], i) * x[k];
+      s1 += readlane_f64(a[k + 1], i) * x[k + 1];
+    }
+    if (i & 1) s0 += readlane_f64(a[i - 1], i) * x[i - 1];
+    const double di = readlane_f64(dmine, i);
+    x[i] = i == r ? di : (i > r ? -(s0 + s1) * di : 0.0);
+  }
+  if (lane < CHB) {
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) Xm[(c0 + i) * CHP + c0 + r] = x[i];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
+                        int* __restrict__ info) {
+  extern __shared__ double cb_lds[];
+  double* Lm = cb_lds;              // Lm[i * CHP + c] = L[i][c] (lower), in place over G
+  double* Xm = Lm + CHN * CHP;      // Xm[i * CHP + c] = (L^-1)[i][c]
+  double* dinvs = Xm + CHN * CHP;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int nb = (l + CHB - 1) / CHB;
+  CHOL_STAMP(0)
+  // every load in flight before the first use: one HBM latency for the whole matrix
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, i = e >> 6, c = e & 63;
+    v[u] = (i < l && c <= i) ? G[(size_t)i * ld + c] : 0.0;
+  }
+  double dg = lane < l ? fabs(G[(size_t)lane * ld + lane]) : 0.0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) dg = fmax(dg, __shfl_xor(dg, off));
   const double floor_s = dg * 1e-13 + 1e-300;
+  const double pad = dg > 0.0 ? dg : 1.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, i = e >> 6, c = e & 63;
+    Lm[i * CHP + c] = (i >= l && i == c) ? pad : v[u];
+    Xm[i * CHP + c] = 0.0;
+  }
+  __syncthreads();
+  CHOL_STAMP(1)
   int bad = 0;
-  for (int j = 0; j < l; ++j) {
-    double s0 = Lc[j * N + i], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int k = 0;
-    for (; k + 15 < j; k += 16) {   // 32 LDS reads in flight per round trip: one wave has nothing else to hide the latency with
-      double p[16], q[16];
+  const int i16 = lane & 15, g4 = lane >> 4;
+  for (int b = 0; b < nb; ++b) {
+    const int c0 = b * CHB;
+    if (wave == 0) {
+      double a[CHB];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { p[u] = Lc[(k + u) * N + i]; q[u] = Lc[(k + u) * N + j]; }
+      for (int c = 0; c < CHB; ++c) a[c] = Lm[lane * CHP + c0 + c];
 #pragma unroll
-      for (int u = 0; u < 16; u += 4) {
-        s0 -= p[u] * q[u];
-        s1 -= p[u + 1] * q[u + 1];
-        s2 -= p[u + 2] * q[u + 2];
-        s3 -= p[u + 3] * q[u + 3];
+      for (int j = 0; j < CHB; ++j) {
+        double piv = readlane_f64(a[j], c0 + j);
+        if (!(piv > floor_s)) { piv = floor_s; bad += 1; }
+        double d, dinv;
+        sqrt_rsqrt(piv, d, dinv);
+        a[j] = lane == c0 + j ? d : a[j] * dinv;
+        if (lane == 0) dinvs[c0 + j] = dinv;
+#pragma unroll
+        for (int c = j + 1; c < CHB; ++c) a[c] -= a[j] * readlane_f64(a[j], c0 + c);
+      }
+#pragma unroll
+      for (int c = 0; c < CHB; ++c)
+        if (lane >= c0 + c) Lm[lane * CHP + c0 + c] = a[c];
+    } else if (wave == 1 && b > 0) {
+      invert_diag_block(Lm, Xm, dinvs, c0 - CHB, lane);
+    }
+    __syncthreads();
+    CHOL_STAMP(2 + 2 * b)
+    // trailing blocks (I, J), b < J <= I < nb:  G_IJ -= P_I P_J^T with P = the block column just finished
+    const int ntb = nb - b - 1, npairs = ntb * (ntb + 1) / 2;
+    for (int p = wave; p < npairs; p += 4) {
+      const int ii = p >= 3 ? 2 : (p >= 1 ? 1 : 0), jj = p - ii * (ii + 1) / 2;
+      const int rI = (b + 1 + ii) * CHB, rJ = (b + 1 + jj) * CHB;
+      d4 acc = d4{0, 0, 0, 0};
+      acc = block_mma(Lm + rI * CHP + c0, CHP, 1, Lm + rJ * CHP + c0, 1, CHP, acc, lane);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = rI + g4 + 4 * reg, col = rJ + i16;
+        if (col <= row) Lm[row * CHP + col] -= acc[reg];
       }
     }
-    for (; k + 3 < j; k += 4) {
-      s0 -= Lc[k * N + i] * Lc[k * N + j];
-      s1 -= Lc[(k + 1) * N + i] * Lc[(k + 1) * N + j];
-      s2 -= Lc[(k + 2) * N + i] * Lc[(k + 2) * N + j];
-      s3 -= Lc[(k + 3) * N + i] * Lc[(k + 3) * N + j];
-    }
-    for (; k < j; ++k) s0 -= Lc[k * N + i] * Lc[k * N + j];
-    const double s = (s0 + s1) + (s2 + s3);
-    double piv = __shfl(s, j);
-    if (!(piv > floor_s)) { piv = floor_s; bad += 1; }
-    const double d = sqrt(piv), dinv = 1.0 / d;
-    Lc[j * N + i] = i == j ? d : (i > j ? s * dinv : 0.0);
-    if (i == j) dinvs[j] = dinv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    CHOL_STAMP(3 + 2 * b)
   }
-  // lane i: column i of L^-1:  x[i] = 1/L[i][i];  x[r] = -(sum_{i<=k<r} L[r][k] x[k]) / L[r][r]
-  for (int r = 0; r < l; ++r) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int k = 0;
-    for (; k + 15 < r; k += 16) {
-      double p[16], q[16];
+  // the last diagonal block is inverted by wave 1 beside the block rows that do not need it yet
+  if (wave == 1) invert_diag_block(Lm, Xm, dinvs, (nb - 1) * CHB, lane);
+  CHOL_STAMP(10)
+  for (int bi = 1; bi < nb; ++bi) {
+    if (bi == nb - 1) __syncthreads();   // X of the last diagonal block
+    const int bj = wave == 0 ? 0 : wave - 1;   // waves 0, 2, 3 take block columns 0, 1, 2
+    if (wave != 1 && bj < bi) {
+      d4 tacc = d4{0, 0, 0, 0};
+      for (int kb = bj; kb < bi; ++kb)
+        tacc = block_mma(Lm + bi * CHB * CHP + kb * CHB, CHP, 1, Xm + kb * CHB * CHP + bj * CHB, CHP, 1, tacc, lane);
+      // D layout: tacc[ks] = T[g + 4 ks][j] -- the B operand of MFMA step ks
+      d4 xacc = d4{0, 0, 0, 0};
+      double a[4];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { p[u] = Lc[(k + u) * N + r]; q[u] = Xc[(k + u) * N + i]; }
+      for (int ks = 0; ks < 4; ++ks) a[ks] = Xm[(bi * CHB + i16) * CHP + bi * CHB + 4 * ks + g4];
 #pragma unroll
-      for (int u = 0; u < 16; u += 4) {
-        s0 += p[u] * q[u];
-        s1 += p[u + 1] * q[u + 1];
-        s2 += p[u + 2] * q[u + 2];
-        s3 += p[u + 3] * q[u + 3];
-      }
+      for (int ks = 0; ks < 4; ++ks) xacc = mfma_f64(a[ks], tacc[ks], xacc);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Xm[(bi * CHB + g4 + 4 * reg) * CHP + bj * CHB + i16] = -xacc[reg];
+      // a block column stays with its wave: the next block row reads what this wave wrote, nothing else's
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    for (; k + 3 < r; k += 4) {
-      s0 += Lc[k * N + r] * Xc[k * N + i];
-      s1 += Lc[(k + 1) * N + r] * Xc[(k + 1) * N + i];
-      s2 += Lc[(k + 2) * N + r] * Xc[(k + 2) * N + i];
-      s3 += Lc[(k + 3) * N + r] * Xc[(k + 3) * N + i];
+    CHOL_STAMP(10 + bi)
+  }
+  __syncthreads();
+  for (int bi = nb; bi < 4; ++bi) { CHOL_STAMP(10 + bi) }
+  // R = L^T (upper): R[r][c] = L[c][r];  R^-1 = (L^-1)^T
+  if (ld == CHN) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = t + u * 256, r = e >> 6, c = e & 63;
+      const bool in = r < l && c < l && c >= r;
+      R[e] = in ? Lm[c * CHP + r] : 0.0;
+      Rinv[e] = in ? Xm[c * CHP + r] : 0.0;
     }
-    for (; k < r; ++k) s0 += Lc[k * N + r] * Xc[k * N + i];
-    const double s = (s0 + s1) + (s2 + s3);
-    const double dinv = dinvs[r];
-    Xc[r * N + i] = r == i ? dinv : (r > i ? -s * dinv : 0.0);
+  } else {
+    for (int e = t; e < ld * ld; e += 256) {
+      const int r = e / ld, c = e % ld;
+      const bool in = r < l && c < l && c >= r;
+      R[e] = in ? Lm[c * CHP + r] : 0.0;
+      Rinv[e] = in ? Xm[c * CHP + r] : 0.0;
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // R = L^T (upper): R[r][c] = L[c][r];  R^-1 = (L^-1)^T: Rinv[r][c] = (L^-1)[c][r]
-  for (int e = i; e < ld * ld; e += N) {
-    const int r = e / ld, c = e % ld;
-    const bool in = r < l && c < l && c >= r;
-    R[e] = in ? Lc[r * N + c] : 0.0;
-    Rinv[e] = in ? Xc[c * N + r] : 0.0;
-  }
-  if (i == 0 && bad) atomicAdd(info, bad);
+  CHOL_STAMP(14)
+  if (t == 0 && bad) atomicAdd(info, bad);
 }
 
 // ---------------------------------------------------------------- panel GEMM
@@ -530,14 +641,13 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
   static const bool general_only = getenv("SAPCA_CHOL_GENERAL") != nullptr;
   if (l <= 64 && !general_only) {
-    constexpr int kWaveLds = (2 * 64 * 64 + 64) * (int)sizeof(double);
     static bool attr = false;
     if (!attr) {
-      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_wave_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds));
+      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_blocked_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCholBlockedLds));
       attr = true;
     }
-    hipLaunchKernelGGL(chol_inv_wave_kernel, dim3(1), dim3(64), kWaveLds, s, G, l, ld, R, Rinv, info);
+    hipLaunchKernelGGL(chol_inv_blocked_kernel, dim3(1), dim3(256), kCholBlockedLds, s, G, l, ld, R, Rinv, info);
     SAPCA_HIP(hipGetLastError());
     return;
   }

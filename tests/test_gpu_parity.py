@@ -121,6 +121,20 @@ def test_normalizer_qr_orthonormal_same_span(session, dtype, tol):
     assert np.array_equal(session.normalize_panel(P, PIN.NONE), P)
 
 
+@pytest.mark.parametrize("l", [1, 7, 16, 17, 33, 48, 60, 64, 90])
+def test_normalizer_every_block_count_of_the_cholesky(session, l):
+    """l <= 64 runs the blocked one-workgroup Cholesky (1-4 blocks of 16 columns, padded), wider panels the general one"""
+    P = synth.gaussian_panel(4000, l, 11).numpy().astype(np.float64)
+    P *= np.logspace(0, 3, l)[None, :]                          # graded column scales
+    Q = session.normalize_panel(P, PIN.QR)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(l), atol=2e-11)
+    q_ref, _ = np.linalg.qr(P)
+    assert O.subspace_angle(Q.T, q_ref.T) < 1e-9
+    # R = Q^T P is upper triangular with a positive diagonal (Cholesky factor of the Gram matrix)
+    Rm = Q.T @ P
+    assert np.allclose(np.tril(Rm, -1), 0, atol=1e-8 * np.abs(Rm).max()) and np.all(np.diag(Rm) > 0)
+
+
 def test_omega_generator_matches_host_function(session):
     om = session.generate_omega(300, 30)
     np.testing.assert_allclose(om, synth.gaussian_panel(300, 30, 42).numpy(), atol=1e-12)
