@@ -199,6 +199,27 @@ def test_fit_with_builtin_omega_converges_to_exact(golden):
     np.testing.assert_allclose(pca.singular_values_(np.float64), g["exact_s"][:k], rtol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rank_deficient_panel_keeps_the_leading_components(dtype):
+    """rank(A - mean) = 4 < l = 13: the panel's Gram matrix is singular, the Cholesky floors the dead pivots
+    (reported through chol_regularised) and the leading components still match the exact SVD"""
+    rng = np.random.default_rng(3)
+    m, n, r, k = 1500, 200, 5, 3
+    U = rng.standard_normal((m, r)) * np.array([9.0, 7.0, 5.0, 3.0, 2.0])
+    W = rng.standard_normal((r, n))
+    D = U @ W
+    c = sp.csr_matrix(D.astype(dtype))                    # dense low-rank matrix stored as CSR
+    A = mat(c.indptr, c.indices, c.data, m, n)
+    pca = _builder(k, 10, 3).build()
+    pca.fit(A)
+    Dc = D.astype(dtype).astype(np.float64)
+    Dc = Dc - Dc.mean(axis=0)
+    _, s_ex, vt_ex = np.linalg.svd(Dc, full_matrices=False)
+    assert np.all(np.isfinite(pca.components_(np.float64)))
+    np.testing.assert_allclose(pca.singular_values_(np.float64), s_ex[:k], rtol=1e-9 if dtype == np.float64 else 2e-4)
+    assert O.subspace_angle(pca.components_(np.float64), vt_ex[:k]) < (1e-7 if dtype == np.float64 else 1e-3)
+
+
 # ------------------------------------------------------------------ G5 vs oracle, device entry points
 @pytest.mark.parametrize("dtype,ang", [(torch.float64, 1e-8), (torch.float32, 1e-4)])
 def test_g5_c1_device_path_vs_oracle(golden, dtype, ang):
