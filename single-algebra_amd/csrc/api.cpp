@@ -366,7 +366,7 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
       const sapca::TiledOp* top = nullptr;
       if constexpr (sizeof(T) == 4) {
         if (want_tiled) {
-          if (sapca::k::build_tiled(A, false, ld, h->tiled_a, h->tb_a, s)) top = &h->tiled_a;   // else: row kernel
+          if (sapca::k::build_tiled(A, false, sapca::k::tiled_geometry((int)l), h->tiled_a, h->tb_a, s)) top = &h->tiled_a;   // else: row kernel
         }
       }
       sapca::k::spmm(A, top, X, ld, Y, ld, ld, mu ? cvec : nullptr, h->opt.spmm_variant, h->split_scratch, s);
@@ -380,7 +380,7 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
       const sapca::TiledOp* top = nullptr;
       if constexpr (sizeof(T) == 4) {
         if (want_tiled) {
-          if (sapca::k::build_tiled(At, false, ld, h->tiled_at, h->tb_at, s)) top = &h->tiled_at;
+          if (sapca::k::build_tiled(At, false, sapca::k::tiled_geometry((int)l), h->tiled_at, h->tb_at, s)) top = &h->tiled_at;
         }
       }
       sapca::k::spmm(At, top, X, ld, Y, ld, ld, (const T*)nullptr, h->opt.spmm_variant, h->split_scratch, s);

@@ -97,7 +97,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
       const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
       if (l >= 1 && l <= 128 && n_kept > 0) {
-        const int ldp = l <= 64 ? 64 : 128;
+        const int ldp = k::tiled_geometry((int)l);
         const double tile_bytes = 80.0 * 1024.0, block_rows = ldp == 64 ? 512.0 : 256.0;
         const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_kept * ldp * 4.0 / tile_bytes);
         const bool dense_enough = (double)nnz * ((double)n_kept / (double)n) * 64.0 >= chunks * tile_bytes;
@@ -293,7 +293,7 @@ void Engine<T>::fit_randomized(H& h) {
   const int l = (int)std::min<int64_t>(l_req, std::min<int64_t>((int64_t)h.m_global, n_used));
   SAPCA_CHECK(l <= 128, SAPCA_ERR_ARG, "n_components + n_oversamples above 128 is not supported");
   const bool tiled = h.tiled_a.valid && h.tiled_at.valid;
-  const int ld = tiled ? h.tiled_a.ldp : (int)round_up(l, 16);
+  const int ld = tiled ? std::max(h.tiled_a.ldp, l <= 64 ? 64 : 128) : (int)round_up(l, 16);
   const int q = (int)h.opt.n_power_iterations;
   const int norm = h.opt.normalizer;
   const bool center = h.opt.center != 0;
@@ -548,8 +548,8 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     key.nnz = (uint64_t)A.nnz; key.mask_version = h.mask_version; key.dtype = kDtype; key.valid = true;
     const bool prepared = h.prep_key == key;
     // the fitted matrix's tile-major format serves the projection sweep too (one row block per workgroup)
-    const TiledOp* top = (prepared && h.tiled_a.valid && h.tiled_a.nsplit == 1 && k <= h.tiled_a.ldp) ? &h.tiled_a : nullptr;
-    if (top) ldk = top->ldp;
+    const TiledOp* top = (prepared && h.tiled_a.valid && h.tiled_a.nsplit == 1 && k <= 128) ? &h.tiled_a : nullptr;
+    if (top) ldk = std::max(top->ldp, k <= 64 ? 64 : 128);
     CsrView<T> Au;
     double* d_cnt = nullptr;
     if (prepared) {

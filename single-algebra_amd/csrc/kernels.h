@@ -77,7 +77,9 @@ void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, in
                     double* sum, double* sumsq, hipStream_t s);
 // number of interleaved column tiles the format uses for an operator with `cols` columns
 int tiled_tile_count(int64_t cols, int ldp);
-void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
+// tile geometry (panel columns held per LDS tile row) for a panel of l columns: 64, two column passes when l > 64
+int tiled_geometry(int l);
+void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s);
 
 // ---- dense.hip -------------------------------------------------------------------------

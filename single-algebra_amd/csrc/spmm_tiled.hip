@@ -332,7 +332,7 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
 
 // out[r][j] = sum_sp part[sp][r][j] - cvec[j]   (fixed order)
 __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t rows, int ldo, int ncols,
-                                    const float* __restrict__ cvec, float* __restrict__ out) {
+                                    const float* __restrict__ cvec, float* __restrict__ out, int ldy) {
   const int64_t total = rows * ldo;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -341,7 +341,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
     if (j >= ncols) continue;
     float s = 0.f;
     for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * total + i];
-    out[i] = s - (cvec ? cvec[j] : 0.f);
+    out[(i / ldo) * ldy + j] = s - (cvec ? cvec[j] : 0.f);
   }
 }
 
@@ -362,6 +362,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 #endif
 constexpr int QGROUPS = 4, QLANES = WAVE / QGROUPS, QWAVES = SAPCA_QWAVES, QTHREADS = QWAVES * WAVE;
 constexpr int Q_TILE_BYTES = 80 * 1024;          // default split of the 160 KiB: 80 KiB panel tile + 79 KiB entry staging
+constexpr int Q_MAX_TILES_RUNS = 9000;           // tile-major builder: its [4][tiles + 1] LDS table stays under 160 KiB
 constexpr int Q_TILE_BYTES_BIG = 96 * 1024;      // for operators whose chunks leave room: fewer, longer tile steps
 constexpr int q_stage_bytes(int tile_bytes) { return LDS_TOTAL - tile_bytes - 1024; }
 constexpr int q_stage_entries(int tile_bytes) { return q_stage_bytes(tile_bytes) / 8 - WAVE; }
@@ -987,14 +988,14 @@ __device__ __forceinline__ void quad_batch(v4f (&acc)[NV], const char* stage_lan
 
 // panel rows t, t + nct, t + 2 nct, ... (clamped: slots past the last row are never referenced)
 template <int N, int LDP>
-__device__ __forceinline__ void load_tile_interleaved(v4f (&r)[N], const float* __restrict__ X, int t, int nct,
+__device__ __forceinline__ void load_tile_interleaved(v4f (&r)[N], const float* __restrict__ X, int ldx, int t, int nct,
                                                       int64_t panel_rows) {
-  constexpr int CPR = LDP / 4;   // 16-byte chunks per panel row
+  constexpr int CPR = LDP / 4;   // 16-byte chunks per panel row (LDP of the panel's ldx columns)
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int j = i * QTHREADS + (int)threadIdx.x;
     const int64_t grow = min((int64_t)(j / CPR) * nct + t, panel_rows - 1);
-    r[i] = *reinterpret_cast<const v4f*>(X + grow * LDP + (j % CPR) * 4);
+    r[i] = *reinterpret_cast<const v4f*>(X + grow * ldx + (j % CPR) * 4);
   }
 }
 
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ void load_tile_interleaved(v4f (&r)[N], const float* 
   {                                                                                                 \
     const int64_t cidx_ = (int64_t)rb * nct + (CT);                                                 \
     const int64_t c_lo_ = chunk_off[cidx_];                                                         \
-    load_tile_interleaved<NP_TILE, LDP>(pt, X, (CT), nct, panel_rows);                              \
+    load_tile_interleaved<NP_TILE, LDP>(pt, X, ldx, (CT), nct, panel_rows);                              \
     load_regs<NP_STAGE, QTHREADS>(ps, reinterpret_cast<const char*>(ent + c_lo_),                   \
                                   max(16, (int)(chunk_off[cidx_ + 1] - c_lo_) * 8));                \
   }
@@ -1018,7 +1019,7 @@ __global__ void __launch_bounds__(QTHREADS)
 spmm_quad_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct, int tc,
                  const int64_t* __restrict__ chunk_off,
                  const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, const Ent* __restrict__ ent,
-                 int64_t panel_rows, const float* __restrict__ X, int nsplit, int tiles_per_split,
+                 int64_t panel_rows, const float* __restrict__ X, int ldx, int nsplit, int tiles_per_split,
                  float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec,
                  int mode) {
   constexpr int NV = LDP / 64;            // b128 reads per panel row per lane
@@ -1123,7 +1124,7 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restric
 #undef SAPCA_QBOOKKEEPING
 
 template <int LDP, bool PREFETCH, int TILE_B>
-void launch_quad(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
+void launch_quad(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int mode,
                  hipStream_t s) {
   static bool attr = false;
   if (!attr) {
@@ -1133,7 +1134,7 @@ void launch_quad(const TiledOp& op, const float* X, float* out, int ldo, int nco
   }
   hipLaunchKernelGGL((spmm_quad_kernel<LDP, PREFETCH, TILE_B>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
                      op.blk_row0, op.row_perm, op.nct, op.tc, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
-                     reinterpret_cast<const Ent*>(op.ent), op.cols, X, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
+                     reinterpret_cast<const Ent*>(op.ent), op.cols, X, ldx, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
                      ncols, cvec, mode);
 }
 
@@ -1204,7 +1205,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
       if (nsplit > 1) nsplit = (int)std::min<int64_t>(nct, nsplit);
     }
   }
-  if (quad && !transposed && (op_cols >= (1 << 24) || nct > 4096)) return false;   // float-reciprocal tile arithmetic, LDS tables of the builder
+  if (quad && !transposed && (op_cols >= (1 << 24) || nct > (rows_tile_major ? Q_MAX_TILES_RUNS : 4096))) return false;   // float-reciprocal tile arithmetic, LDS tables of the builders
   const float inv_nct = 1.0f / (float)nct;
   int32_t* d_seg = nullptr;
   if (!transposed) {
@@ -1345,7 +1346,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
                            (double)total <= 0.85 * QF_CAP_MAX * ((double)op_rows / 4.0) && nct <= 768;
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : QF_CAP_MAX;
-  const bool runs_fill = quad && !transposed && rows_tile_major && nct <= 4000;
+  const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
   if (packed_rows && !runs_fill) return false;
   if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(Ent), s));
   else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
@@ -1358,11 +1359,17 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   if (transposed)
     hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
-  else if (runs_fill)
+  else if (runs_fill) {
+    static bool attr = false;
+    if (!attr) {   // [4][nct + 1] row-segment table: above 64 KiB from 4096 tiles on
+      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&quad_fill_runs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((size_t)4 * (Q_MAX_TILES_RUNS + 1) * sizeof(int32_t))));
+      attr = true;
+    }
     hipLaunchKernelGGL(quad_fill_runs_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, d_perm, nct,
                        inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
-  else if (staged_fill)
+  } else if (staged_fill)
     hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)qf_cap * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
                        d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
@@ -1398,44 +1405,60 @@ int tiled_tile_count(int64_t cols, int ldp) {
   return (int)((cols + tc - 1) / tc);
 }
 
-void spmm_tiled(const TiledOp& op, const float* X, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
+void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s) {
   SAPCA_CHECK(op.valid, SAPCA_ERR_ARG, "tiled sweep: operator not built");
+  SAPCA_CHECK(ldx == op.ldp || (op.fmt == 1 && op.ldp == 64 && ldx == 128), SAPCA_ERR_ARG,
+              "tiled sweep: panel leading dimension does not match the operator's tile geometry");
   static const int mode = getenv("SAPCA_TILED_MODE") ? atoi(getenv("SAPCA_TILED_MODE")) : 0;  // ablation switches (debug)
-  float* out = Y;
-  int ldo = ldy, nc = ncols;
-  float* part = nullptr;
-  if (op.nsplit > 1) {
-    SAPCA_CHECK(ldy == op.ldp, SAPCA_ERR_ARG, "tiled sweep with a split tile range needs ldy == panel leading dimension");
-    part = scratch.as<float>((size_t)op.nsplit * op.rows * op.ldp);
-    out = part;
-    ldo = op.ldp;
-    nc = op.ldp;
-  }
+  // A 128-wide panel over the 64-wide tile geometry goes through in two column passes: twice the entry
+  // traffic, but a tile holds twice the panel rows of the 128-wide geometry (half the tiles, less quad
+  // padding, chunks that amortise their refill) -- what keeps wide panels on sparse operators (C5) staged.
+  const int passes = ldx / op.ldp;
+  float* part = op.nsplit > 1 ? scratch.as<float>((size_t)op.nsplit * op.rows * op.ldp) : nullptr;
   const bool pf = !(mode & 4);
-  if (op.fmt == 1) {
-    const bool big = op.tile_bytes == Q_TILE_BYTES_BIG;
-    if (op.ldp == 64 && pf && big) launch_quad<64, true, Q_TILE_BYTES_BIG>(op, X, out, ldo, nc, cvec, mode, s);
-    else if (op.ldp == 64 && pf) launch_quad<64, true, Q_TILE_BYTES>(op, X, out, ldo, nc, cvec, mode, s);
-    else if (op.ldp == 64 && big) launch_quad<64, false, Q_TILE_BYTES_BIG>(op, X, out, ldo, nc, cvec, mode, s);
-    else if (op.ldp == 64) launch_quad<64, false, Q_TILE_BYTES>(op, X, out, ldo, nc, cvec, mode, s);
-    else if (big) launch_quad<128, false, Q_TILE_BYTES_BIG>(op, X, out, ldo, nc, cvec, mode, s);
-    else launch_quad<128, false, Q_TILE_BYTES>(op, X, out, ldo, nc, cvec, mode, s);
-  } else if (op.ldp == 64 && op.slots == 4) {
-    if (pf) launch_tiled<64, 4, true>(op, X, out, ldo, nc, cvec, mode, s);
-    else launch_tiled<64, 4, false>(op, X, out, ldo, nc, cvec, mode, s);
-  } else if (op.ldp == 64) {
-    if (pf) launch_tiled<64, 2, true>(op, X, out, ldo, nc, cvec, mode, s);
-    else launch_tiled<64, 2, false>(op, X, out, ldo, nc, cvec, mode, s);
-  } else {
-    launch_tiled<128, 2, false>(op, X, out, ldo, nc, cvec, mode, s);
-  }
-  if (op.nsplit > 1) {
-    const int64_t total = op.rows * (int64_t)op.ldp;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
-                       op.ldp, ncols, cvec, Y);
+  for (int pass = 0; pass < passes; ++pass) {
+    const int c0 = pass * op.ldp;
+    if (c0 >= ncols && pass > 0) break;
+    const float* Xp = X + c0;
+    const float* cv = cvec ? cvec + c0 : nullptr;
+    const int ncp = std::min(ncols - c0, op.ldp);
+    float* out = Y + c0;
+    int ldo = ldy, nc = ncp;
+    if (op.nsplit > 1) {
+      out = part;
+      ldo = op.ldp;
+      nc = op.ldp;
+    }
+    if (op.fmt == 1) {
+      const bool big = op.tile_bytes == Q_TILE_BYTES_BIG;
+      if (op.ldp == 64 && pf && big) launch_quad<64, true, Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
+      else if (op.ldp == 64 && pf) launch_quad<64, true, Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
+      else if (op.ldp == 64 && big) launch_quad<64, false, Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
+      else if (op.ldp == 64) launch_quad<64, false, Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
+      else if (big) launch_quad<128, false, Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
+      else launch_quad<128, false, Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
+    } else if (op.ldp == 64 && op.slots == 4) {
+      if (pf) launch_tiled<64, 4, true>(op, Xp, out, ldo, nc, cv, mode, s);
+      else launch_tiled<64, 4, false>(op, Xp, out, ldo, nc, cv, mode, s);
+    } else if (op.ldp == 64) {
+      if (pf) launch_tiled<64, 2, true>(op, Xp, out, ldo, nc, cv, mode, s);
+      else launch_tiled<64, 2, false>(op, Xp, out, ldo, nc, cv, mode, s);
+    } else {
+      launch_tiled<128, 2, false>(op, Xp, out, ldo, nc, cv, mode, s);
+    }
+    if (op.nsplit > 1) {
+      const int64_t total = op.rows * (int64_t)op.ldp;
+      hipLaunchKernelGGL(split_reduce_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
+                         op.ldp, ncp, cv, Y + c0, ldy);
+    }
   }
   SAPCA_HIP(hipGetLastError());
+}
+
+int tiled_geometry(int l) {
+  static const bool wide = getenv("SAPCA_TILED_GEOM128") != nullptr;   // the 128-wide tile geometry for l > 64 (one pass)
+  return (l > 64 && wide) ? 128 : 64;
 }
 
 }  // namespace k
