@@ -362,7 +362,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, 
 #endif
 constexpr int QGROUPS = 4, QLANES = WAVE / QGROUPS, QWAVES = SAPCA_QWAVES, QTHREADS = QWAVES * WAVE;
 constexpr int Q_TILE_BYTES = 80 * 1024;          // default split of the 160 KiB: 80 KiB panel tile + 79 KiB entry staging
-constexpr int Q_MAX_TILES_RUNS = 9000;           // tile-major builder: its [4][tiles + 1] LDS table stays under 160 KiB
+constexpr int Q_MAX_TILES_RUNS = 16384;          // tile-major builder (bounded by the tile arithmetic's float reciprocal and the index tables' size)
 constexpr int Q_TILE_BYTES_BIG = 96 * 1024;      // for operators whose chunks leave room: fewer, longer tile steps
 constexpr int q_stage_bytes(int tile_bytes) { return LDS_TOTAL - tile_bytes - 1024; }
 constexpr int q_stage_entries(int tile_bytes) { return q_stage_bytes(tile_bytes) / 8 - WAVE; }
@@ -732,6 +732,10 @@ natural_quad_slots_kernel(const int64_t* __restrict__ ptr, int64_t rows, unsigne
 
 // Streaming fill: a workgroup owns a quad; every (quad, tile) segment is four contiguous source runs
 // interleaved step by step ([k][g]) and padded with zero entries, written as one contiguous piece.
+// SEG_LDS: the quad's four rows of seg are staged in LDS (few tiles: the table is small and the
+// workgroups stay many per CU); otherwise every lane reads its row's bounds from global memory one
+// tile step ahead (many tiles: a [4][tiles + 1] table would leave one or two workgroups per CU).
+template <bool SEG_LDS>
 __global__ void __launch_bounds__(256)
 quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
                       const uint64_t* __restrict__ packed, const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
@@ -744,22 +748,46 @@ quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const int qrows = min(4, nrows - 4 * qd);
   const int64_t s0q = (int64_t)row0 + 4 * qd;   // first slot position of the quad; slot -> row through perm
-  for (int i = threadIdx.x; i < 4 * (nct + 1); i += 256) {
-    const int g = i / (nct + 1);
-    const int64_t rg = g < qrows ? (perm ? (int64_t)perm[s0q + g] : s0q + g) : 0;
-    sg_lds[i] = g < qrows ? seg[rg * (nct + 1) + (i - g * (nct + 1))] : 0;
+  if (SEG_LDS) {
+    for (int i = threadIdx.x; i < 4 * (nct + 1); i += 256) {
+      const int g = i / (nct + 1);
+      const int64_t rg = g < qrows ? (perm ? (int64_t)perm[s0q + g] : s0q + g) : 0;
+      sg_lds[i] = g < qrows ? seg[rg * (nct + 1) + (i - g * (nct + 1))] : 0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int g = lane & 3, k0 = lane >> 2;   // lane -> (step k0 + 16*pass, row g)
-  const int64_t base = g < qrows ? ptr[perm ? (int64_t)perm[s0q + g] : s0q + g] : 0;
-  const int32_t* mysg = sg_lds + g * (nct + 1);
+  const int64_t myrow = g < qrows ? (perm ? (int64_t)perm[s0q + g] : s0q + g) : -1;
+  const int64_t base = myrow >= 0 ? ptr[myrow] : 0;
+  const int32_t* mysg = SEG_LDS ? sg_lds + g * (nct + 1) : seg + (myrow >= 0 ? myrow : 0) * (nct + 1);
   const int64_t* __restrict__ coff = chunk_off + (int64_t)rb * nct;
   const uint32_t* __restrict__ qoff = quad_off + ((int64_t)rb * Q_BLOCK_QUADS + qd) * nct;
+  int s_nx = 0, e_nx = 0;
+  int64_t d_nx = 0;
+  if (!SEG_LDS && wave < nct) {
+    s_nx = myrow >= 0 ? mysg[wave] : 0;
+    e_nx = myrow >= 0 ? mysg[wave + 1] : 0;
+    d_nx = coff[wave] + qoff[wave];
+  }
   for (int t = wave; t < nct; t += 4) {
-    const int s0 = mysg[t], len = mysg[t + 1] - s0;
+    int s0, len;
+    Ent* dst;
+    if (SEG_LDS) {
+      s0 = mysg[t];
+      len = mysg[t + 1] - s0;
+      dst = ent + coff[t] + qoff[t];
+    } else {
+      s0 = s_nx;
+      len = e_nx - s_nx;
+      dst = ent + d_nx;
+      if (t + 4 < nct) {
+        s_nx = myrow >= 0 ? mysg[t + 4] : 0;
+        e_nx = myrow >= 0 ? mysg[t + 5] : 0;
+        d_nx = coff[t + 4] + qoff[t + 4];
+      }
+    }
     int qmax = max(len, __shfl_xor(len, 1));
     qmax = max(qmax, __shfl_xor(qmax, 2));
-    Ent* dst = ent + coff[t] + qoff[t];
     for (int k = k0; k < qmax; k += 16) {
       Ent x{0u, 0.f};
       if (k < len) {
@@ -1360,15 +1388,14 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
     hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (runs_fill) {
-    static bool attr = false;
-    if (!attr) {   // [4][nct + 1] row-segment table: above 64 KiB from 4096 tiles on
-      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&quad_fill_runs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((size_t)4 * (Q_MAX_TILES_RUNS + 1) * sizeof(int32_t))));
-      attr = true;
-    }
-    hipLaunchKernelGGL(quad_fill_runs_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
-                       (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, d_perm, nct,
-                       inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+    const int seg_lds_max = getenv("SAPCA_RUNS_SEG_LDS_MAX") ? atoi(getenv("SAPCA_RUNS_SEG_LDS_MAX")) : 1024;   // tiles; above: bounds from global memory
+    if (nct <= seg_lds_max)
+      hipLaunchKernelGGL(quad_fill_runs_kernel<true>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
+                         (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, d_perm, nct,
+                         inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+    else
+      hipLaunchKernelGGL(quad_fill_runs_kernel<false>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), 0, s, S.ptr, S.idx, S.val,
+                         packed_rows, d_seg, d_blk, d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   } else if (staged_fill)
     hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)qf_cap * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,

@@ -545,6 +545,24 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
 
 
+def test_tile_major_builder_with_and_without_its_lds_table(monkeypatch):
+    """A^T's format: the row-segment bounds staged in LDS (few tiles) or read from global memory one tile ahead
+    (many tiles, C4/C5) -- the same bytes, hence bit-identical fits"""
+    m, n, k, p, q = 9000, 700, 8, 6, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.06, k, seed=12, dtype=torch.float32))
+    om = synth.gaussian_panel(n, k + p, 3).numpy()
+    out = []
+    for lim in ("100000", "0"):
+        monkeypatch.setenv("SAPCA_RUNS_SEG_LDS_MAX", lim)
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(mat(ptr, idx, val, m, n))
+        out.append((pca.singular_values_(np.float64), pca.components_(np.float64), t))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
+
+
 def test_staged_and_direct_format_fill_agree(monkeypatch):
     """the LDS-staged builder of A's tile-major format and the direct one write the same bytes: bit-identical
     fits; a matrix with a few very long rows sends some quads down the direct route inside the staged kernel"""
