@@ -268,37 +268,11 @@ __device__ __forceinline__ void invert_diag_block(const double* Lm, double* Xm, 
   }
 }
 
-__global__ void __launch_bounds__(256)
-chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
-                        int* __restrict__ info) {
-  extern __shared__ double cb_lds[];
-  double* Lm = cb_lds;              // Lm[i * CHP + c] = L[i][c] (lower), in place over G
-  double* Xm = Lm + CHN * CHP;      // Xm[i * CHP + c] = (L^-1)[i][c]
-  double* dinvs = Xm + CHN * CHP;
+// Factor + invert the (16 nb) x (16 nb) matrix in Lm (lower triangle, upper part zero) -> L in Lm, L^-1 in Xm
+// (Xm zeroed by the caller).  All 256 threads call it; it ends with a workgroup barrier.
+template <bool STAMPS>
+__device__ __forceinline__ void chol_inv_core(double* Lm, double* Xm, double* dinvs, int nb, double floor_s, int& bad) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int nb = (l + CHB - 1) / CHB;
-  CHOL_STAMP(0)
-  // every load in flight before the first use: one HBM latency for the whole matrix
-  double v[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int e = t + u * 256, i = e >> 6, c = e & 63;
-    v[u] = (i < l && c <= i) ? G[(size_t)i * ld + c] : 0.0;
-  }
-  double dg = lane < l ? fabs(G[(size_t)lane * ld + lane]) : 0.0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) dg = fmax(dg, __shfl_xor(dg, off));
-  const double floor_s = dg * 1e-13 + 1e-300;
-  const double pad = dg > 0.0 ? dg : 1.0;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int e = t + u * 256, i = e >> 6, c = e & 63;
-    Lm[i * CHP + c] = (i >= l && i == c) ? pad : v[u];
-    Xm[i * CHP + c] = 0.0;
-  }
-  __syncthreads();
-  CHOL_STAMP(1)
-  int bad = 0;
   const int i16 = lane & 15, g4 = lane >> 4;
   for (int b = 0; b < nb; ++b) {
     const int c0 = b * CHB;
@@ -324,7 +298,7 @@ chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __r
       invert_diag_block(Lm, Xm, dinvs, c0 - CHB, lane);
     }
     __syncthreads();
-    CHOL_STAMP(2 + 2 * b)
+    if (STAMPS) { CHOL_STAMP(2 + 2 * b) }
     // trailing blocks (I, J), b < J <= I < nb:  G_IJ -= P_I P_J^T with P = the block column just finished
     const int ntb = nb - b - 1, npairs = ntb * (ntb + 1) / 2;
     for (int p = wave; p < npairs; p += 4) {
@@ -339,11 +313,11 @@ chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __r
       }
     }
     __syncthreads();
-    CHOL_STAMP(3 + 2 * b)
+    if (STAMPS) { CHOL_STAMP(3 + 2 * b) }
   }
   // the last diagonal block is inverted by wave 1 beside the block rows that do not need it yet
   if (wave == 1) invert_diag_block(Lm, Xm, dinvs, (nb - 1) * CHB, lane);
-  CHOL_STAMP(10)
+  if (STAMPS) { CHOL_STAMP(10) }
   for (int bi = 1; bi < nb; ++bi) {
     if (bi == nb - 1) __syncthreads();   // X of the last diagonal block
     const int bj = wave == 0 ? 0 : wave - 1;   // waves 0, 2, 3 take block columns 0, 1, 2
@@ -364,10 +338,46 @@ chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __r
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    CHOL_STAMP(10 + bi)
+    if (STAMPS) { CHOL_STAMP(10 + bi) }
   }
   __syncthreads();
-  for (int bi = nb; bi < 4; ++bi) { CHOL_STAMP(10 + bi) }
+  if (STAMPS) {
+    for (int bi = nb; bi < 4; ++bi) { CHOL_STAMP(10 + bi) }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
+                        int* __restrict__ info) {
+  extern __shared__ double cb_lds[];
+  double* Lm = cb_lds;              // Lm[i * CHP + c] = L[i][c] (lower), in place over G
+  double* Xm = Lm + CHN * CHP;      // Xm[i * CHP + c] = (L^-1)[i][c]
+  double* dinvs = Xm + CHN * CHP;
+  const int t = threadIdx.x, lane = t & 63;
+  const int nb = (l + CHB - 1) / CHB;
+  CHOL_STAMP(0)
+  // every load in flight before the first use: one HBM latency for the whole matrix
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, i = e >> 6, c = e & 63;
+    v[u] = (i < l && c <= i) ? G[(size_t)i * ld + c] : 0.0;
+  }
+  double dg = lane < l ? fabs(G[(size_t)lane * ld + lane]) : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dg = fmax(dg, __shfl_xor(dg, off));
+  const double floor_s = dg * 1e-13 + 1e-300;
+  const double pad = dg > 0.0 ? dg : 1.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, i = e >> 6, c = e & 63;
+    Lm[i * CHP + c] = (i >= l && i == c) ? pad : v[u];
+    Xm[i * CHP + c] = 0.0;
+  }
+  __syncthreads();
+  CHOL_STAMP(1)
+  int bad = 0;
+  chol_inv_core<true>(Lm, Xm, dinvs, nb, floor_s, bad);
   // R = L^T (upper): R[r][c] = L[c][r];  R^-1 = (L^-1)^T
   if (ld == CHN) {
 #pragma unroll
@@ -386,6 +396,136 @@ chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __r
     }
   }
   CHOL_STAMP(14)
+  if (t == 0 && bad) atomicAdd(info, bad);
+}
+
+// 64 < l <= 128 (ld = 128): the same core on the two 64 x 64 diagonal halves of G = [G11 . ; G21 G22],
+//   L11 = chol(G11),  L21 = G21 L11^-T,  L22 = chol(G22 - L21 L21^T),  X21 = -X22 (L21 X11),
+// with the 64 x 64 products as 16 x 16 blocks on the matrix cores; four 64 x 65 LDS buffers (133 KiB).
+// sum over kb < nk of A_blk(kb) B_blk(kb) for one 16 x 16 output block
+__device__ __forceinline__ d4 mm_block(const double* pa, int sai, int sak, const double* pb, int sbk, int sbj, int nk, int lane) {
+  d4 acc = d4{0, 0, 0, 0};
+  for (int kb = 0; kb < nk; ++kb) acc = block_mma(pa + kb * CHB * sak, sai, sak, pb + kb * CHB * sbk, sbk, sbj, acc, lane);
+  return acc;
+}
+
+constexpr int kChol128Lds = (4 * CHN * CHP + CHN) * (int)sizeof(double);
+
+__global__ void __launch_bounds__(256)
+chol_inv_blocked128_kernel(const double* __restrict__ G, int l, double* __restrict__ R, double* __restrict__ Rinv,
+                           int* __restrict__ info) {
+  constexpr int LD = 128;
+  extern __shared__ double cb_lds[];
+  double* B0 = cb_lds;
+  double* B1 = B0 + CHN * CHP;
+  double* B2 = B1 + CHN * CHP;
+  double* B3 = B2 + CHN * CHP;
+  double* dinvs = B3 + CHN * CHP;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int l2 = l - CHN, nb2 = (l2 + CHB - 1) / CHB;
+  double dg = fabs(G[(size_t)lane * LD + lane]);
+  if (lane + CHN < l) dg = fmax(dg, fabs(G[(size_t)(lane + CHN) * LD + lane + CHN]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dg = fmax(dg, __shfl_xor(dg, off));
+  const double floor_s = dg * 1e-13 + 1e-300;
+  const double pad = dg > 0.0 ? dg : 1.0;
+  int bad = 0;
+  // ---- G11 -> L11 (B0), X11 (B1); G21 -> B2 meanwhile
+  {
+    double v[16], w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = t + u * 256, i = e >> 6, c = e & 63;
+      v[u] = c <= i ? G[(size_t)i * LD + c] : 0.0;
+      w[u] = i < l2 ? G[(size_t)(CHN + i) * LD + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = t + u * 256, i = e >> 6, c = e & 63;
+      B0[i * CHP + c] = v[u];
+      B1[i * CHP + c] = 0.0;
+      B2[i * CHP + c] = w[u];
+    }
+  }
+  __syncthreads();
+  chol_inv_core<false>(B0, B1, dinvs, 4, floor_s, bad);
+  // outputs of the first half: R[0:64][0:64] = L11^T, Rinv likewise, and the zero block below them
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, r = e >> 6, c = e & 63;
+    const bool in = c >= r;
+    R[(size_t)r * LD + c] = in ? B0[c * CHP + r] : 0.0;
+    Rinv[(size_t)r * LD + c] = in ? B1[c * CHP + r] : 0.0;
+    R[(size_t)(CHN + r) * LD + c] = 0.0;
+    Rinv[(size_t)(CHN + r) * LD + c] = 0.0;
+  }
+  // ---- L21 = G21 X11^T -> B3   (L21[i][j] = sum_k G21[i][k] X11[j][k], k <= j)
+  for (int blk = wave; blk < 16; blk += 4) {
+    const int I = blk >> 2, J = blk & 3;
+    const d4 acc = mm_block(B2 + I * CHB * CHP, CHP, 1, B1 + J * CHB * CHP, 1, CHP, J + 1, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) B3[(I * CHB + g4 + 4 * reg) * CHP + J * CHB + i16] = acc[reg];
+  }
+  __syncthreads();
+  // ---- S = G22 - L21 L21^T -> B0 (lower), R[0:64][64:128] = L21^T; B2 becomes the zeroed X22
+  {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = t + u * 256, i = e >> 6, c = e & 63;
+      v[u] = (i < l2 && c <= i) ? G[(size_t)(CHN + i) * LD + CHN + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = t + u * 256, i = e >> 6, c = e & 63;
+      B0[i * CHP + c] = (i >= l2 && i == c) ? pad : v[u];
+      B2[i * CHP + c] = 0.0;
+      R[(size_t)i * LD + CHN + c] = c < l2 ? B3[c * CHP + i] : 0.0;   // (r = i, column 64 + c)
+    }
+  }
+  __syncthreads();
+  for (int p = wave; p < 10; p += 4) {   // lower block pairs (I, J), J <= I < 4
+    const int I = p >= 6 ? 3 : (p >= 3 ? 2 : (p >= 1 ? 1 : 0)), J = p - I * (I + 1) / 2;
+    const d4 acc = mm_block(B3 + I * CHB * CHP, CHP, 1, B3 + J * CHB * CHP, 1, CHP, 4, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = I * CHB + g4 + 4 * reg, col = J * CHB + i16;
+      if (col <= row) B0[row * CHP + col] -= acc[reg];
+    }
+  }
+  __syncthreads();
+  chol_inv_core<false>(B0, B2, dinvs, nb2, floor_s, bad);   // L22 in B0, X22 in B2
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, r = e >> 6, c = e & 63;
+    const bool in = r < l2 && c < l2 && c >= r;
+    R[(size_t)(CHN + r) * LD + CHN + c] = in ? B0[c * CHP + r] : 0.0;
+    Rinv[(size_t)(CHN + r) * LD + CHN + c] = in ? B2[c * CHP + r] : 0.0;
+  }
+  __syncthreads();
+  // ---- W = L21 X11 -> B0;  X21 = -X22 W -> B3;  Rinv[0:64][64:128] = X21^T
+  for (int blk = wave; blk < 16; blk += 4) {
+    const int I = blk >> 2, J = blk & 3;
+    // X11 is lower triangular: block row kb of its block column J is zero for kb < J
+    const d4 acc = mm_block(B3 + I * CHB * CHP + J * CHB, CHP, 1, B1 + J * CHB * CHP + J * CHB, CHP, 1, 4 - J, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) B0[(I * CHB + g4 + 4 * reg) * CHP + J * CHB + i16] = acc[reg];
+  }
+  __syncthreads();
+  for (int blk = wave; blk < 16; blk += 4) {
+    const int I = blk >> 2, J = blk & 3;
+    // X22 is lower triangular: block column kb of its block row I is zero for kb > I
+    const d4 acc = mm_block(B2 + I * CHB * CHP, CHP, 1, B0 + J * CHB, CHP, 1, I + 1, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) B3[(I * CHB + g4 + 4 * reg) * CHP + J * CHB + i16] = -acc[reg];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = t + u * 256, r = e >> 6, c = e & 63;
+    Rinv[(size_t)r * LD + CHN + c] = c < l2 ? B3[c * CHP + r] : 0.0;
+  }
   if (t == 0 && bad) atomicAdd(info, bad);
 }
 
@@ -648,6 +788,17 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
       attr = true;
     }
     hipLaunchKernelGGL(chol_inv_blocked_kernel, dim3(1), dim3(256), kCholBlockedLds, s, G, l, ld, R, Rinv, info);
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
+  if (l > 64 && l <= 128 && ld == 128 && !general_only) {
+    static bool attr = false;
+    if (!attr) {
+      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_blocked128_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kChol128Lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL(chol_inv_blocked128_kernel, dim3(1), dim3(256), kChol128Lds, s, G, l, R, Rinv, info);
     SAPCA_HIP(hipGetLastError());
     return;
   }

@@ -8,7 +8,7 @@
 #include <vector>
 
 int main(int argc, char** argv) {
-  const int l = argc > 1 ? atoi(argv[1]) : 60, ld = 64;
+  const int l = argc > 1 ? atoi(argv[1]) : 60, ld = l <= 64 ? 64 : 128;
   std::mt19937_64 g(5);
   std::normal_distribution<double> nd;
   std::vector<double> P(400 * l), G((size_t)ld * ld, 0.0);
