@@ -487,6 +487,26 @@ def test_fit_wide_panel_k100():
         np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), O.explained_variance_ratio(want.explained_variance), atol=2e-5)
 
 
+def test_wide_panel_fit_transform_two_column_passes():
+    """l = 100 over the 64-wide tile geometry: two column passes per sweep, on an operator whose A^T side splits
+    its tile range (900 rows -> 2 row blocks) and through the projection (k = 90 > 64); against the row kernel
+    and the oracle"""
+    m, n, k, p, q = 40000, 900, 90, 10, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.03, 12, seed=17, dtype=torch.float32))
+    om = synth.gaussian_panel(n, k + p, 5).numpy()
+    want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    res = []
+    for variant in (1, 2):
+        pca = _builder(k, p, q).spmm_variant(variant).build().set_omega(om)
+        t = pca.fit_transform(mat(ptr, idx, val, m, n))
+        assert t.shape == (m, k) and np.isfinite(t).all()
+        np.testing.assert_allclose(pca.singular_values_(np.float64)[:12], want.singular_values[:12], rtol=1e-4)
+        res.append((pca.singular_values_(np.float64), t))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=2e-4)
+    # the leading, well separated components project the same way with either kernel
+    np.testing.assert_allclose(res[1][1][:, :12], res[0][1][:, :12], atol=2e-3 * np.abs(res[0][1][:, :12]).max())
+
+
 def test_panel_width_limit_is_an_error():
     ptr, idx, val = csr_np(synth.flat_csr(400, 300, 0.1, seed=2, dtype=torch.float32))
     pca = _builder(120, 10, 1).build()
