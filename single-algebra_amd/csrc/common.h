@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -73,6 +74,21 @@ struct CsrView {
 };
 
 // Tile-major companion of an f32 CSR operator for the LDS-staged sweep (spmm_tiled.hip).
+// Dynamic LDS above the default limit has to be enabled per kernel AND per device: a process may drive
+// handles on several devices.  `state` is one static per call site (per template instantiation).
+struct LdsAttrState {
+  std::atomic<int> bytes[64];
+  LdsAttrState() { for (auto& b : bytes) b.store(0, std::memory_order_relaxed); }
+};
+inline void ensure_dynamic_lds(const void* kernel, size_t bytes, LdsAttrState& state) {
+  int dev = 0;
+  SAPCA_HIP(hipGetDevice(&dev));
+  std::atomic<int>& have = state.bytes[dev & 63];
+  if (have.load(std::memory_order_acquire) >= (int)bytes) return;
+  SAPCA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have.store((int)bytes, std::memory_order_release);
+}
+
 // Page-locked host staging buffer (grow-only), for the chunked upload of the host entry points.
 struct PinnedBuf {
   void* p = nullptr;

@@ -728,24 +728,16 @@ template <typename T, int NT>
 void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, hipStream_t s) {
   constexpr int NPAIR = NT * (NT + 1) / 2;
   const size_t lds = (size_t)NPAIR * 256 * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_kernel<T, NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static LdsAttrState attr;
+  if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_kernel<T, NT>), lds, attr);
   hipLaunchKernelGGL((gram_kernel<T, NT>), dim3(nblocks), dim3(256), lds, s, P, rows, ld, slabs);
 }
 
 template <typename T, int NTO>
 void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s) {
   const size_t lds = (size_t)ld * ldo * sizeof(double);
-  static size_t attr_bytes = 0;
-  if (lds > 48 * 1024 && lds > attr_bytes) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_bytes = lds;
-  }
+  static LdsAttrState attr;
+  if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>), lds, attr);
   const int64_t ntiles = (rows + 15) / 16;
   int blocks = (int)((ntiles + 3) / 4);
   if (blocks > 1024) blocks = 1024;
@@ -781,34 +773,22 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
   static const bool general_only = getenv("SAPCA_CHOL_GENERAL") != nullptr;
   if (l <= 64 && !general_only) {
-    static bool attr = false;
-    if (!attr) {
-      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_blocked_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kCholBlockedLds));
-      attr = true;
-    }
+    static LdsAttrState attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_blocked_kernel), kCholBlockedLds, attr);
     hipLaunchKernelGGL(chol_inv_blocked_kernel, dim3(1), dim3(256), kCholBlockedLds, s, G, l, ld, R, Rinv, info);
     SAPCA_HIP(hipGetLastError());
     return;
   }
   if (l > 64 && l <= 128 && ld == 128 && !general_only) {
-    static bool attr = false;
-    if (!attr) {
-      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_blocked128_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kChol128Lds));
-      attr = true;
-    }
+    static LdsAttrState attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_blocked128_kernel), kChol128Lds, attr);
     hipLaunchKernelGGL(chol_inv_blocked128_kernel, dim3(1), dim3(256), kChol128Lds, s, G, l, R, Rinv, info);
     SAPCA_HIP(hipGetLastError());
     return;
   }
   const size_t lds = ((size_t)l * (l + 1) + l) * sizeof(double);
-  static size_t attr_bytes = 0;
-  if (lds > 48 * 1024 && lds > attr_bytes) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_inv_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_bytes = lds;
-  }
+  static LdsAttrState attr;
+  if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_kernel), lds, attr);
   hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds, s, G, l, ld, R, Rinv, info);
   SAPCA_HIP(hipGetLastError());
 }

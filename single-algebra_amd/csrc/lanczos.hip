@@ -260,12 +260,8 @@ void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s)
   const size_t xbytes = (size_t)A.cols * sizeof(double);
   static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
   if (!no_lds && xbytes <= 150 * 1024 && A.rows >= 4096) {
-    static bool attr[2] = {false, false};
-    if (!attr[sizeof(T) == 8]) {
-      SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    150 * 1024));
-      attr[sizeof(T) == 8] = true;
-    }
+    static LdsAttrState attr;   // one per instantiation of this function template
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T>), 150 * 1024, attr);
     hipLaunchKernelGGL((spmv_ldsx_kernel<T>), dim3(256), dim3(1024), xbytes, s, A.ptr, A.idx, A.val, A.rows, A.cols, x, y);
     return;
   }
@@ -277,12 +273,8 @@ void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s)
     int rpw = (int)((A.rows + 256 * SLICE_WAVES - 1) / (256 * SLICE_WAVES));
     if (rpw < 1) rpw = 1;
     if (rpw <= SLICE_MAX_RPW && rpw * (nslices + 1) <= WAVE) {
-      static bool attr2[2] = {false, false};
-      if (!attr2[sizeof(T) == 8]) {
-        SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sliced_kernel<T>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr2[sizeof(T) == 8] = true;
-      }
+      static LdsAttrState attr2;
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_sliced_kernel<T>), 150 * 1024, attr2);
       const int rows_per_block = SLICE_WAVES * rpw;
       hipLaunchKernelGGL((spmv_sliced_kernel<T>), dim3((unsigned)((A.rows + rows_per_block - 1) / rows_per_block)),
                          dim3(SLICE_WAVES * WAVE), (size_t)slice * sizeof(double), s, A.ptr, A.idx, A.val, A.rows, A.cols, slice,

@@ -1154,12 +1154,8 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restric
 template <int LDP, bool PREFETCH, int TILE_B>
 void launch_quad(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int mode,
                  hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_quad_kernel<LDP, PREFETCH, TILE_B>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr = true;
-  }
+  static LdsAttrState attr;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_quad_kernel<LDP, PREFETCH, TILE_B>), LDS_TOTAL, attr);
   hipLaunchKernelGGL((spmm_quad_kernel<LDP, PREFETCH, TILE_B>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
                      op.blk_row0, op.row_perm, op.nct, op.tc, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
                      reinterpret_cast<const Ent*>(op.ent), op.cols, X, ldx, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
@@ -1169,12 +1165,8 @@ void launch_quad(const TiledOp& op, const float* X, int ldx, float* out, int ldo
 template <int LDP, int SLOTS, bool PREFETCH>
 void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
                   hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    SAPCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tiled_kernel<LDP, SLOTS, PREFETCH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr = true;
-  }
+  static LdsAttrState attr;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_tiled_kernel<LDP, SLOTS, PREFETCH>), LDS_TOTAL, attr);
   hipLaunchKernelGGL((spmm_tiled_kernel<LDP, SLOTS, PREFETCH>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(waves_for(SLOTS) * WAVE), LDS_TOTAL,
                      s, op.blk_row0, op.nct, op.tc, op.chunk_off, op.wave_off, op.steps,
                      reinterpret_cast<const Ent*>(op.ent), op.cols, X, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
