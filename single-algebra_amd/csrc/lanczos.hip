@@ -156,21 +156,33 @@ spmv_sliced_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
   }
 }
 
-// h[i] (+)= sum_r V[i][r] w[r], i < nvec: one block per basis vector
-__global__ void __launch_bounds__(256)
+// h[i] (+)= sum_r V[i][r] w[r], i < nvec: one block per basis vector; four independent partial sums per
+// thread keep four loads in flight (a single dependent chain made this kernel 25 us for 18k elements)
+constexpr int GEMV_T_THREADS = 512;
+__global__ void __launch_bounds__(GEMV_T_THREADS)
 gemv_t_kernel(const double* __restrict__ V, int64_t len, int nvec, const double* __restrict__ w,
               double* __restrict__ h, int accumulate) {
-  __shared__ double red[4];
+  __shared__ double red[GEMV_T_THREADS / WAVE];
   const int i = blockIdx.x;
   const double* v = V + (int64_t)i * len;
-  double s = 0;
-  for (int64_t r = threadIdx.x; r < len; r += blockDim.x) s = fma(v[r], w[r], s);
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int64_t r = threadIdx.x;
+  for (; r + 3 * GEMV_T_THREADS < len; r += 4 * GEMV_T_THREADS) {
+    s0 = fma(v[r], w[r], s0);
+    s1 = fma(v[r + GEMV_T_THREADS], w[r + GEMV_T_THREADS], s1);
+    s2 = fma(v[r + 2 * GEMV_T_THREADS], w[r + 2 * GEMV_T_THREADS], s2);
+    s3 = fma(v[r + 3 * GEMV_T_THREADS], w[r + 3 * GEMV_T_THREADS], s3);
+  }
+  for (; r < len; r += GEMV_T_THREADS) s0 = fma(v[r], w[r], s0);
+  double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double t = red[0] + red[1] + red[2] + red[3];
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < GEMV_T_THREADS / WAVE; ++k) t += red[k];
     h[i] = accumulate ? h[i] + t : t;
   }
 }
@@ -203,8 +215,12 @@ norm2_kernel(const double* __restrict__ w, int64_t len, double* __restrict__ par
 __global__ void __launch_bounds__(256)
 scale_kernel(const double* __restrict__ w, int64_t len, const double* __restrict__ partial, int nparts,
              double* __restrict__ beta_out, double* __restrict__ vnext) {
+  // the partial sums of norm2_kernel, reduced in a fixed order by every wave (nparts <= 256)
+  const int lane = threadIdx.x & (WAVE - 1);
   double s = 0;
-  for (int i = 0; i < nparts; ++i) s += partial[i];
+  for (int i = lane; i < nparts; i += WAVE) s += partial[i];
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
   const double beta = sqrt(s);
   if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = beta;
   const double inv = beta > 0 ? 1.0 / beta : 0.0;
@@ -358,9 +374,9 @@ void lanczos_fit(sapca_handle_s& h) {
     const double* vj = V + (size_t)j * len;
     apply_B(vj, w);
     const int nvec = (int)(j + 1);
-    hipLaunchKernelGGL(gemv_t_kernel, dim3(nvec), dim3(256), 0, s, V, len, nvec, w, h1, 0);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(nvec), dim3(GEMV_T_THREADS), 0, s, V, len, nvec, w, h1, 0);
     hipLaunchKernelGGL(gemv_n_sub_kernel, dim3(grid1(len)), dim3(256), 0, s, V, len, nvec, h1, w);
-    hipLaunchKernelGGL(gemv_t_kernel, dim3(nvec), dim3(256), 0, s, V, len, nvec, w, h2, 0);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(nvec), dim3(GEMV_T_THREADS), 0, s, V, len, nvec, w, h2, 0);
     hipLaunchKernelGGL(gemv_n_sub_kernel, dim3(grid1(len)), dim3(256), 0, s, V, len, nvec, h2, w);
     hipLaunchKernelGGL(pick_alpha_kernel, dim3(1), dim3(1), 0, s, h1, h2, (int)j, alpha);
     hipLaunchKernelGGL(norm2_kernel, dim3(nparts), dim3(256), 0, s, w, len, partial);
