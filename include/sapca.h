@@ -16,9 +16,14 @@
  *     where one exists).
  *   - _f32/_f64 pairs mirror the reference's generic T (f32/f64 in practice).
  *   - host CSR inputs use nalgebra_sparse::CsrMatrix's own layout: row_offsets
- *     and col_indices are usize (uint64_t), zero-copy from Rust.
+ *     and col_indices are usize (uint64_t), zero-copy from Rust.  The host entry
+ *     points check what keeps every kernel inside the arrays (offsets start at 0,
+ *     end at nnz and never decrease; columns < n) and return SAPCA_ERR_ARG otherwise;
+ *     columns sorted and unique within a row is CsrMatrix's own invariant and is
+ *     relied upon, not checked (unsorted rows give wrong numbers, not stray accesses).
  *   - "device" entry points take HBM-resident CSR (int64 row offsets, int32 column
- *     indices) and device output buffers; they are what bench.py times.
+ *     indices) and device output buffers; they are what bench.py times.  Device
+ *     arrays are trusted (no validation pass).
  *   - inputs are borrowed for the duration of a call; outputs are written into
  *     caller-allocated buffers.
  *   - a handle is not thread-safe; distinct handles may be used concurrently.

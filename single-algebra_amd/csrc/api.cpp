@@ -79,6 +79,11 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
                   const uint64_t* col_indices, const T* values) {
   SAPCA_CHECK(row_offsets != nullptr && (nnz == 0 || (col_indices && values)), SAPCA_ERR_ARG, "null CSR array");
   SAPCA_CHECK(row_offsets[0] == 0 && row_offsets[m] == nnz, SAPCA_ERR_ARG, "row_offsets do not span [0, nnz]");
+  {   // with monotone offsets and in-range columns (checked below) no kernel can leave the arrays
+    bool monotone = true;
+    for (uint64_t i = 0; i < m; ++i) monotone &= row_offsets[i] <= row_offsets[i + 1];
+    SAPCA_CHECK(monotone, SAPCA_ERR_ARG, "row_offsets must be non-decreasing");
+  }
   SAPCA_CHECK(n < (1ull << 31) && m < (1ull << 31), SAPCA_ERR_ARG, "more than 2^31-1 rows or columns is not supported");
   hipStream_t s = h->stream;
   h->prep_key.valid = false;  // the upload buffers are about to hold a different matrix

@@ -323,6 +323,20 @@ def test_error_behaviour():
     assert e.value.status == L.ERR_SVD
 
 
+def test_malformed_host_csr_is_refused(session):
+    """arrays a CsrMatrix could never hold: offsets that go backwards, a column past n -- an error, not a stray access"""
+    X = np.ones((4, 2))
+    val = np.ones(5)
+    idx = np.array([0, 1, 2, 3, 0], dtype=np.int64)
+    with pytest.raises(L.SapcaError, match="non-decreasing") as e:
+        session.spmm(np.array([0, 5, 3, 5], dtype=np.int64), idx, val, 3, 4, X)
+    assert e.value.status == L.ERR_ARG
+    with pytest.raises(L.SapcaError, match="do not span"):
+        session.spmm(np.array([0, 2, 3, 4], dtype=np.int64), idx, val, 3, 4, X)
+    with pytest.raises(L.SapcaError, match="column index out of range"):
+        session.spmm(np.array([0, 2, 3, 5], dtype=np.int64), np.array([0, 1, 2, 3, 4], dtype=np.int64), val, 3, 4, X)
+
+
 def test_explained_variance_ratio_sums_to_one_q4():
     ptr, idx, val = csr_np(synth.gapped_csr(2000, 500, 0.08, 6, seed=3, dtype=torch.float32))
     pca = _builder(6, 6, 2).build()
