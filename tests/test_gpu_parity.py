@@ -369,6 +369,87 @@ def test_properties_at_scale():
     tc = pc.fit_transform(x).double()
     np.testing.assert_allclose((tc ** 2).sum(0).cpu().numpy() / (m - 1), pc.explained_variance_(np.float64), rtol=2e-3)
 
+def test_properties_at_the_c2_size():
+    """BASELINE's C2 (200k x 20k f32, 1.2e8 stored entries, k=50, p=10, q=4, QR) -- too big for the oracle, so
+    the size-independent properties: orthonormal components, fit_transform == fit + transform, bitwise
+    reproducibility, ratios summing to one (Q4), the variance identity of the CENTERED projection, and the
+    residual check  ||Ac^T u_i - sigma_i v_i|| <= 1e-3 sigma_i  with u_i = Ac v_i / sigma_i computed by the
+    stage-level sweeps on the same resident matrix."""
+    m, n, k, p, q = 200_000, 20_000, 50, 10, 4
+    dev = synth.gapped_csr(m, n, 0.03, k, seed=42, dtype=torch.float32, device="cuda")
+    x = sapca.DeviceCsr(*dev, (m, n))
+    pca = _builder(k, p, q).build()
+    t1 = pca.fit_transform(x)
+    c = pca.components_(np.float64)
+    np.testing.assert_allclose(c @ c.T, np.eye(k), atol=5e-5)
+    assert torch.equal(t1, pca.transform(x))
+    pca_b = _builder(k, p, q).build()
+    t3 = pca_b.fit_transform(x)
+    assert torch.equal(t1, t3) and np.array_equal(pca_b.components_(), pca.components_())
+    r = pca.explained_variance_ratio(np.float64)
+    assert abs(r.sum() - 1) < 1e-5 and np.all(np.diff(pca.explained_variance_(np.float64)) <= 0)
+    pc = _builder(k, p, q).transform_semantics(L.TRANSFORM_CENTERED).build()
+    tc = pc.fit_transform(x).double()          # = U S: column i has norm sigma_i and the columns are orthogonal
+    sv = pc.singular_values_(np.float64)
+    np.testing.assert_allclose((tc ** 2).sum(0).sqrt().cpu().numpy(), sv, rtol=1e-3)
+    g = (tc.T @ tc).cpu().numpy() / np.outer(sv, sv)
+    np.testing.assert_allclose(g, np.eye(k), atol=2e-3)
+    # singular pair residual through A^T: Ac^T (Ac v_i) = sigma_i^2 v_i, Ac^T y = A^T y - mean * sum(y)
+    ptr, idx, val = dev
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), ptr[1:] - ptr[:-1])
+    mean = torch.as_tensor(pc.mean_(np.float64), device="cuda")
+    V = torch.as_tensor(pc.components_(np.float64), device="cuda")
+    for i in (0, k // 2, k - 1):
+        y = tc[:, i]
+        z = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, idx.long(), val.double() * y[rows]) - mean * y.sum()
+        resid = (z - sv[i] ** 2 * V[i]).norm().item() / sv[i] ** 2
+        assert resid < 2e-3, (i, resid)
+
+
+
+def test_properties_at_the_c3_size():
+    """BASELINE's C3 (200k x 30k f64, 60 % feature mask, Lanczos k=30): exact integer mask maps, orthonormal
+    components with svd_flip signs, descending singular values, and the eigen-residual of the UNCENTRED masked
+    operator (Q1)  ||A'^T A' v_i - sigma_i^2 v_i|| <= 1e-4 sigma_i^2  (las2's kappa is 1e-5 on the Ritz value),
+    the masked transform (Q3) against torch index arithmetic on the same resident arrays."""
+    m, n, k = 200_000, 30_000, 30
+    ptr, idx, val = synth.gapped_csr(m, n, 0.03, k, seed=42, centred=False, dtype=torch.float64, device="cuda")
+    mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
+    x = sapca.DeviceCsr(ptr, idx, val, (m, n))
+    est = sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).svd_method(SVDMethod.Lanczos()).build()
+    t = est.fit_transform(x)
+    cols, o2m = est.mask_index_maps()
+    want_cols = np.flatnonzero(mask)
+    assert np.array_equal(cols, want_cols)                                   # ascending, bit-exact
+    want_o2m = np.full(n, -1, np.int64)
+    want_o2m[want_cols] = np.arange(want_cols.size)
+    assert np.array_equal(o2m, want_o2m)
+    c = est.components_(np.float64)
+    n_used = want_cols.size
+    assert c.shape == (k, n_used)
+    np.testing.assert_allclose(c @ c.T, np.eye(k), atol=1e-9)
+    assert np.all(c[np.arange(k), np.argmax(np.abs(c), 1)] > 0)
+    sv = est.singular_values_(np.float64)
+    assert np.all(np.diff(sv) < 0)
+    # residual on the GPU with torch: entries of kept columns only, columns renumbered
+    o2m_d = torch.as_tensor(want_o2m, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(m, device="cuda"), ptr[1:] - ptr[:-1])
+    cj = o2m_d[idx.long()]
+    keep = cj >= 0
+    rows_k, cj_k, val_k = rows[keep], cj[keep], val[keep]
+    V = torch.as_tensor(c, device="cuda")
+    for i in (0, k // 2, k - 1):
+        y = torch.zeros(m, dtype=torch.float64, device="cuda").index_add_(0, rows_k, val_k * V[i][cj_k])
+        z = torch.zeros(n_used, dtype=torch.float64, device="cuda").index_add_(0, cj_k, val_k * y[rows_k])
+        resid = (z - sv[i] ** 2 * V[i]).norm().item() / sv[i] ** 2
+        assert resid < 1e-4, (i, resid)
+    # Q3: t_ik = sum over stored, kept entries of (a_ij - mean_j) V[k, idx(j)]
+    mean = torch.as_tensor(est.mean_(np.float64), device="cuda")
+    assert mean.numel() == n                                               # unmasked indexing (sparse_masked/mod.rs:291)
+    i = 3
+    want = torch.zeros(m, dtype=torch.float64, device="cuda").index_add_(0, rows_k, (val_k - mean[idx.long()[keep]]) * V[i][cj_k])
+    np.testing.assert_allclose(t[:, i].cpu().numpy(), want.cpu().numpy(), atol=1e-9 * float(want.abs().max()))
+
 
 # ------------------------------------------------------------------ G6: Lanczos (uncentred: quirk Q1)
 @pytest.mark.parametrize("dtype,srel,ang", [(torch.float64, 1e-5, 1e-4), (torch.float32, 1e-4, 1e-4)])
