@@ -348,8 +348,8 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
     CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
     hipStream_t s = h->stream;
     // spmm_variant == 2 exercises the LDS-staged sweep on its own (f32 only): panels padded to 64/128
-    bool want_tiled = false;
-    if constexpr (sizeof(T) == 4) want_tiled = h->opt.spmm_variant == 2;
+    bool want_tiled = h->opt.spmm_variant == 2;
+    if (sizeof(T) == 8 && l > 64) want_tiled = false;   // f64: staged sweep for panels of up to 64 columns
     const int ld = want_tiled ? (l <= 64 ? 64 : 128) : (int)sapca::round_up((int64_t)l, 16);
     const uint64_t in_rows = transposed ? m : n, out_rows = transposed ? n : m;
     T* stage = h->scratch2.as<T>(std::max<uint64_t>(in_rows * l, out_rows * l) + n + 2 * 128);
@@ -373,6 +373,8 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
         if (want_tiled) {
           if (sapca::k::build_tiled(A, false, sapca::k::tiled_geometry((int)l), h->tiled_a, h->tb_a, s)) top = &h->tiled_a;   // else: row kernel
         }
+      } else {
+        if (want_tiled && sapca::k::build_tiled(A, 64, h->tiled_a, h->tb_a, s)) top = &h->tiled_a;
       }
       sapca::k::spmm(A, top, X, ld, Y, ld, ld, mu ? cvec : nullptr, h->opt.spmm_variant, h->split_scratch, s);
     } else {
@@ -387,6 +389,8 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
         if (want_tiled) {
           if (sapca::k::build_tiled(At, false, sapca::k::tiled_geometry((int)l), h->tiled_at, h->tb_at, s)) top = &h->tiled_at;
         }
+      } else {
+        if (want_tiled && sapca::k::build_tiled(At, 64, h->tiled_at, h->tb_at, s)) top = &h->tiled_at;
       }
       sapca::k::spmm(At, top, X, ld, Y, ld, ld, (const T*)nullptr, h->opt.spmm_variant, h->split_scratch, s);
       if (mu) {

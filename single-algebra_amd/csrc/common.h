@@ -118,7 +118,8 @@ struct PinnedBuf {
 struct TiledOp {
   bool valid = false;
   int64_t rows = 0, cols = 0, total_entries = 0;
-  int ldp = 0;              // panel leading dimension (floats) the format was built for: 64 or 128
+  int ldp = 0;              // panel leading dimension (elements) the format was built for: 64 or 128 (f32), 64 (f64)
+  int elem = 4;             // bytes per value and panel element: 4 (f32) or 8 (f64)
   int tc = 0, nct = 0;      // panel rows per column tile, number of tiles
   int nrb = 0;              // row blocks (one workgroup each)
   int nsplit = 1, tiles_per_split = 0;
@@ -130,7 +131,7 @@ struct TiledOp {
   const int64_t* chunk_off = nullptr;  // [nrb*nct+1] entry offsets
   const uint32_t* wave_off = nullptr;  // [nrb*nct][8]
   const uint8_t* steps = nullptr;      // [nrb*nct][256]
-  const void* ent = nullptr;           // {u32 lds byte offset, f32 value}
+  const void* ent = nullptr;           // {u32 lds byte offset, f32 value} or {u32 offset, u32 pad, f64 value}
 };
 struct TiledBuffers {
   DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens;

@@ -92,21 +92,26 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   // the row-gather kernel when a chunk carries enough entries to amortise that fill (measured: 64 tile
   // bytes per entry or less -> clearly faster; 164 -> no gain, 4x the prepare time).
   int tiled_ldp = 0;
-  if constexpr (sizeof(T) == 4) {
-    if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
-      const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
-      const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
-      if (l >= 1 && l <= 128 && n_kept > 0) {
-        const int ldp = k::tiled_geometry((int)l);
-        const double tile_bytes = 80.0 * 1024.0, block_rows = ldp == 64 ? 512.0 : 256.0;
-        const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_kept * ldp * 4.0 / tile_bytes);
-        const bool dense_enough = (double)nnz * ((double)n_kept / (double)n) * 64.0 >= chunks * tile_bytes;
-        if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
-      }
+  if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
+    const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
+    const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
+    const int64_t l_max = sizeof(T) == 4 ? 128 : 64;   // f64: one geometry, panels of up to 64 columns
+    if (l >= 1 && l <= l_max && n_kept > 0) {
+      const int ldp = sizeof(T) == 4 ? k::tiled_geometry((int)l) : 64;
+      const double row_bytes = (double)ldp * sizeof(T);
+      const double tile_bytes = 80.0 * 1024.0, block_rows = row_bytes == 256.0 ? 512.0 : 256.0;
+      const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_kept * row_bytes / tile_bytes);
+      // f64: the row kernel gathers 512 bytes per entry, the staged sweep pays off a little earlier (200k x 20k at
+      // 3 %: 67 tile bytes per entry, 5.4 -> 1.9 ms per sweep).  Small operators stay on the row kernel: below a few
+      // million entries the format build and the per-workgroup tile refills cost more than the gather (10k x 2k at 5 %:
+      // 1.2 ms per fit_transform with the row kernel, 1.7 ms staged).
+      const double entries = (double)nnz * ((double)n_kept / (double)n);
+      const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes && entries >= 4e6;
+      if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
     }
   }
   const bool from_at = getenv("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
-  const bool at_tile_major = tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
+  const bool at_tile_major = sizeof(T) == 4 && tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
 
   CsrView<T> At;
   const uint64_t* at_packed = nullptr;
@@ -127,7 +132,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   // A's format does not depend on the transposition: build it on a side stream while the sort runs on the
   // main one (both are memory-latency bound and overlap well); the main stream joins before the first sweep.
   bool a_built_aside = false, ok_a_aside = false;
-  if constexpr (sizeof(T) == 4) {
+  {
     if (tiled_ldp != 0 && !masked && getenv("SAPCA_PREPARE_SERIAL") == nullptr) {
       if (!h.stream2) {
         SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
@@ -137,7 +142,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       SAPCA_HIP(hipEventRecord(h.ev_fork, s));               // A is ready on the main stream at this point...
       SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
       h.tiled_a = TiledOp();
-      ok_a_aside = k::build_tiled(A, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+      if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(A, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+      else ok_a_aside = k::build_tiled(A, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
       SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));       // ...and the main stream waits for it at the end of prepare()
       a_built_aside = true;
     }
@@ -238,6 +244,17 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       }
       if (h.opt.verbose)
         fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
+                ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
+                ok_at ? "ok" : "no", h.tiled_at.nrb, h.tiled_at.nct, h.tiled_at.nsplit, (long long)h.tiled_at.total_entries);
+      if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }
+    }
+  } else {
+    if (tiled_ldp != 0 && n_used > 0) {
+      Scope sc(h, C_PREPARE);
+      const bool ok_a = a_built_aside ? ok_a_aside : k::build_tiled(view(h.a_used), tiled_ldp, h.tiled_a, h.tb_a, s);
+      const bool ok_at = ok_a && k::build_tiled(view(h.at_used), tiled_ldp, h.tiled_at, h.tb_at, s);
+      if (h.opt.verbose)
+        fprintf(stderr, "sapca: tile-major formats (f64): A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
                 ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
                 ok_at ? "ok" : "no", h.tiled_at.nrb, h.tiled_at.nct, h.tiled_at.nsplit, (long long)h.tiled_at.total_entries);
       if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }

@@ -71,6 +71,9 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                  bool rows_tile_major = false, const uint64_t* packed_rows = nullptr,   // packed_rows: S.idx / S.val are not
                  bool allow_big_tile = true,                                             // filled, read (row << 32 | value) instead
                  bool seg_ready = false);   // buf.seg already holds the per-row tile index (at_stats_index)
+// The same format with f64 values for panels of 64 f64 columns (512-byte rows: the tile geometry of the
+// 128-float panels); built from a CSR in natural row order by the direct fill.
+bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
 // Column statistics of A (row sums / sums of squares of the packed tile-major A^T rows, same summation order as
 // row_sums) and, in the same pass, the per-row tile index build_tiled(..., rows_tile_major, packed, ., seg_ready) needs.
 void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, int64_t cols, int ldp, TiledBuffers& buf,
@@ -80,6 +83,8 @@ int tiled_tile_count(int64_t cols, int ldp);
 // tile geometry (panel columns held per LDS tile row) for a panel of l columns: 64, two column passes when l > 64
 int tiled_geometry(int l);
 void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
+                hipStream_t s);
+void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
                 hipStream_t s);
 
 // ---- dense.hip -------------------------------------------------------------------------

@@ -141,10 +141,18 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
   if (A.rows == 0) return;
   if constexpr (sizeof(T) == 4) {
     // variant 1 forces the row kernel; otherwise the LDS-staged sweep runs whenever its format exists
-    const bool geom_ok = tiled && (tiled->ldp == ldx || (tiled->fmt == 1 && tiled->ldp == 64 && ldx == 128));
+    const bool geom_ok = tiled && tiled->elem == 4 && (tiled->ldp == ldx || (tiled->fmt == 1 && tiled->ldp == 64 && ldx == 128));
     if (variant != 1 && tiled && tiled->valid && geom_ok && tiled->rows == A.rows && tiled->cols == A.cols) {
       spmm_tiled(*tiled, reinterpret_cast<const float*>(X), ldx, reinterpret_cast<float*>(Y), ldy, ncols,
                  reinterpret_cast<const float*>(cvec), scratch, s);
+      return;
+    }
+  } else {
+    // f64: the staged sweep exists for panels of 64 columns (512-byte rows)
+    if (variant != 1 && tiled && tiled->valid && tiled->elem == 8 && tiled->ldp == ldx && tiled->rows == A.rows &&
+        tiled->cols == A.cols) {
+      spmm_tiled(*tiled, reinterpret_cast<const double*>(X), ldx, reinterpret_cast<double*>(Y), ldy, ncols,
+                 reinterpret_cast<const double*>(cvec), scratch, s);
       return;
     }
   }

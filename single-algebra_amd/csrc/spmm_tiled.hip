@@ -59,6 +59,9 @@ constexpr int STAGE_BYTES = LDS_TOTAL - TILE_BYTES - 1024;   // entry staging ca
 constexpr int STAGE_ENTRIES = STAGE_BYTES / 8 - WAVE;        // keep one chunk of slack for read-ahead
 
 struct Ent { uint32_t off; float val; };
+struct EntD { uint32_t off; uint32_t pad; double val; };   // the same entry for f64 values (16 bytes)
+template <typename VT> struct EntOf { typedef Ent type; };
+template <> struct EntOf<double> { typedef EntD type; };
 
 // ---------------------------------------------------------------------------------- builder
 // seg[r][t] (t = 0..nct) = number of entries of row r with col < t*TC  (prep.hip: tile_index_kernel)
@@ -331,17 +334,18 @@ spmm_tiled_kernel(const int32_t* __restrict__ blk_row0, int nct, int tc, const i
 }
 
 // out[r][j] = sum_sp part[sp][r][j] - cvec[j]   (fixed order)
-__global__ void split_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t rows, int ldo, int ncols,
-                                    const float* __restrict__ cvec, float* __restrict__ out, int ldy) {
+template <typename VT>
+__global__ void split_reduce_kernel(const VT* __restrict__ part, int nsplit, int64_t rows, int ldo, int ncols,
+                                    const VT* __restrict__ cvec, VT* __restrict__ out, int ldy) {
   const int64_t total = rows * ldo;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < total; i += stride) {
     const int j = (int)(i % ldo);
     if (j >= ncols) continue;
-    float s = 0.f;
+    VT s = 0;
     for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * total + i];
-    out[(i / ldo) * ldy + j] = s - (cvec ? cvec[j] : 0.f);
+    out[(i / ldo) * ldy + j] = s - (cvec ? cvec[j] : (VT)0);
   }
 }
 
@@ -457,11 +461,13 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
 
 // one wave per row: the k-th entry (in column order) that the row has in tile t goes to slot
 // (k*4 + g) of its quad's segment in that tile's chunk (g = row mod 4 within the block)
+template <typename VT>
 __global__ void __launch_bounds__(256)
-quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const VT* __restrict__ val,
                  int64_t rows, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nrb, int nct,
                  float inv_nct, int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
-                 Ent* __restrict__ ent) {
+                 typename EntOf<VT>::type* __restrict__ ent) {
+  typedef typename EntOf<VT>::type E;
   extern __shared__ uint32_t cnt_all[];   // per wave and tile: slot of the row's next entry (relative to the block's first chunk)
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   uint32_t* cnt = cnt_all + (size_t)wave * nct;
@@ -483,24 +489,24 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
   for (int t = lane; t < nct; t += WAVE) cnt[t] = (uint32_t)(coff[t] - block_base) + qoff[t] + g;
   __builtin_amdgcn_wave_barrier();
   const int64_t e0 = ptr[r], e1 = ptr[r + 1];
-  Ent* __restrict__ out = ent + block_base;
+  E* __restrict__ out = ent + block_base;
   // batches of 64 entries in column order; within a batch the LDS atomic hands out the ranks of
   // equal tiles (a fixed function of the input: the format is reproducible run to run)
   for (int64_t eb = e0; eb < e1; eb += 8 * WAVE) {   // 8 batches loaded ahead: one round trip per 512 entries
     int c[8];
-    float v[8];
+    VT v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t e = eb + u * WAVE + lane;
       c[u] = e < e1 ? idx[e] : -1;
-      v[u] = e < e1 ? val[e] : 0.f;
+      v[u] = e < e1 ? val[e] : (VT)0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (c[u] >= 0) {
         int i, t;
         divmod_small(c[u], nct, inv_nct, i, t);
-        Ent x;
+        E x = E();
         x.off = (uint32_t)i * (uint32_t)ldp_bytes;
         x.val = v[u];
         out[atomicAdd(&cnt[t], 4u)] = x;
@@ -1162,6 +1168,135 @@ void launch_quad(const TiledOp& op, const float* X, int ldx, float* out, int ldo
                      ncols, cvec, mode);
 }
 
+// ---- the same sweep for f64 panels and values ------------------------------------------------------
+// A 64-column f64 panel row is 512 bytes: the tile geometry of the 128-float panels (160 rows per
+// 80 KiB tile, 4 rows per lane group, 256 rows per workgroup).  A lane holds the doubles 2q, 2q+1 and
+// 32+2q, 32+2q+1 of its row (two ds_read_b128); entries are 16 bytes {offset, pad, f64 value}.
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+template <int U>
+__device__ __forceinline__ void quad_batch_f64(v2d (&acc)[2], const char* stage_lane, const char* tile_lane) {
+  u4v e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = *reinterpret_cast<const u4v*>(stage_lane + u * (QGROUPS * 16));
+  v2d w[U][2];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) w[u][v] = *reinterpret_cast<const v2d*>(tile_lane + e[u].x + v * 256);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double val = __hiloint2double((int)e[u].w, (int)e[u].z);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[v] += val * w[u][v];
+  }
+}
+
+template <int TILE_B>
+__global__ void __launch_bounds__(QTHREADS)
+spmm_quad_f64_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct,
+                     const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ wave_off,
+                     const uint16_t* __restrict__ steps, const EntD* __restrict__ ent, int64_t panel_rows,
+                     const double* __restrict__ X, int ldx, int nsplit, int tiles_per_split, double* __restrict__ out,
+                     int64_t out_rows_total, int ldo, int ncols, const double* __restrict__ cvec) {
+  constexpr int RG = q_rows_per_group(128);
+  constexpr int STAGE_B = q_stage_bytes(TILE_B);
+  constexpr int NP_TILE = TILE_B / (QTHREADS * 16), NP_STAGE = (STAGE_B + QTHREADS * 16 - 1) / (QTHREADS * 16);
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* tile = lds;
+  char* stage = lds + TILE_B;
+  const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int g = lane / QLANES, q = lane % QLANES;
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  const int nquads = (nrows + 3) / 4;
+  const int quad0 = q_first(wave, nquads), my_quads = q_first(wave + 1, nquads) - quad0;   // <= RG
+  const int my_rows = min(nrows, 4 * (quad0 + my_quads)) - 4 * quad0;
+  const char* tl = tile + q * 16;
+
+  v2d acc[RG][2];
+#pragma unroll
+  for (int i = 0; i < RG; ++i)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[i][v] = v2d(0.0);
+
+  for (int ct = ct0; ct < ct1; ++ct) {
+    const int64_t cidx = (int64_t)rb * nct + ct;
+    const int64_t c_lo = chunk_off[cidx];
+    const int cnt_v = lane < my_quads ? (int)steps[cidx * Q_BLOCK_QUADS + quad0 + lane] : 0;
+    const unsigned woff = wave_off[cidx * QWAVES + wave];
+    {
+      v4f pt[NP_TILE], ps[NP_STAGE];
+      // the panel as 128 floats per row: the same interleaved 16-byte chunks
+      load_tile_interleaved<NP_TILE, 128>(pt, reinterpret_cast<const float*>(X), 2 * ldx, ct, nct, panel_rows);
+      load_regs<NP_STAGE, QTHREADS>(ps, reinterpret_cast<const char*>(ent + c_lo), max(16, (int)(chunk_off[cidx + 1] - c_lo) * 16));
+      __syncthreads();  // the previous tile's readers are done
+      store_regs<NP_TILE, QTHREADS>(pt, tile, TILE_B);
+      store_regs<NP_STAGE, QTHREADS>(ps, stage, STAGE_B);
+      __syncthreads();
+    }
+    if (my_quads > 0) {
+      const char* sl = stage + (size_t)woff * 16 + g * 16;
+#pragma unroll
+      for (int j = 0; j < RG; ++j) {
+        int n = __builtin_amdgcn_readlane(cnt_v, j);
+        while (n >= 4) {
+          quad_batch_f64<4>(acc[j], sl, tl);
+          sl += 4 * QGROUPS * 16;
+          n -= 4;
+        }
+        if (n >= 2) {
+          quad_batch_f64<2>(acc[j], sl, tl);
+          sl += 2 * QGROUPS * 16;
+          n -= 2;
+        }
+        if (n) {
+          quad_batch_f64<1>(acc[j], sl, tl);
+          sl += QGROUPS * 16;
+        }
+      }
+    }
+  }
+
+  // lane (g, q) holds columns 2q, 2q+1 and 32+2q, 32+2q+1 of row 4j+g of its wave
+  double* dst_base = out + (nsplit > 1 ? (int64_t)sp * out_rows_total * ldo : 0);
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int col = v * 32 + q * 2;
+    double cv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cv[i] = (cvec && nsplit == 1 && col + i < ncols) ? cvec[col + i] : 0.0;
+#pragma unroll
+    for (int j = 0; j < RG; ++j) {
+      const int r = 4 * j + g;
+      if (r < my_rows) {
+        const int64_t spos = (int64_t)row0 + 4 * quad0 + r;   // slot position -> output row
+        double* y = dst_base + (perm ? (int64_t)perm[spos] : spos) * ldo + col;
+        if (col + 1 < ncols) {
+          v2d o = acc[j][v];
+          o.x -= cv[0]; o.y -= cv[1];
+          *reinterpret_cast<v2d*>(y) = o;
+        } else if (col < ncols) {
+          y[0] = acc[j][v].x - cv[0];
+        }
+      }
+    }
+  }
+}
+
+template <int TILE_B>
+void launch_quad_f64(const TiledOp& op, const double* X, int ldx, double* out, int ldo, int ncols, const double* cvec,
+                     hipStream_t s) {
+  static LdsAttrState attr;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_quad_f64_kernel<TILE_B>), LDS_TOTAL, attr);
+  hipLaunchKernelGGL((spmm_quad_f64_kernel<TILE_B>), dim3((unsigned)(op.nrb * op.nsplit)), dim3(QTHREADS), LDS_TOTAL, s,
+                     op.blk_row0, op.row_perm, op.nct, op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps),
+                     reinterpret_cast<const EntD*>(op.ent), op.cols, X, ldx, op.nsplit, op.tiles_per_split, out, op.rows, ldo,
+                     ncols, cvec);
+}
+
 template <int LDP, int SLOTS, bool PREFETCH>
 void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int ncols, const float* cvec, int mode,
                   hipStream_t s) {
@@ -1176,15 +1311,24 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 }  // namespace
 
 // ---------------------------------------------------------------------------------- host side
-bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                 bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready) {
-  SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension must be 64 or 128");
+namespace {
+// VT = float: every route below.  VT = double: the quad format through the direct fill only (the tile-major /
+// packed-row routes and the LDS-staged fill carry f32 values); its 64-column panel rows are 512 bytes, so
+// the geometry is that of the 128-float panels -- `ldp` below is the row length in FLOAT units.
+template <typename VT>
+bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp& op, TiledBuffers& buf, hipStream_t s,
+                   bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready) {
+  typedef typename EntOf<VT>::type E;
+  constexpr bool f32 = sizeof(VT) == 4;
+  const int ldp = ldp_elems * (int)sizeof(VT) / 4;
+  SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel rows must be 256 or 512 bytes");
   op = TiledOp();
+  if (!f32 && (transposed || rows_tile_major || packed_rows)) return false;
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
   // the operator is S, or S^T built straight from S (quad format only)
   const int64_t op_rows = transposed ? S.cols : S.rows, op_cols = transposed ? S.rows : S.cols;
   static const int fmt_env = getenv("SAPCA_TILED_FMT") ? atoi(getenv("SAPCA_TILED_FMT")) : 1;
-  const bool quad = fmt_env == 1;   // 1: a row per 16-lane group (default); 0: two half-waves per row
+  const bool quad = fmt_env == 1 || !f32;   // 1: a row per 16-lane group (default); 0: two half-waves per row
   int tile_bytes = quad ? Q_TILE_BYTES : TILE_BYTES;
   int tc = tile_bytes / (ldp * 4);
   if (transposed && (!quad || (tc + 63) / 64 > TQ_NI)) return false;
@@ -1199,7 +1343,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   const int waves = quad ? QWAVES : waves_for(slots);
   const int block_rows = quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
                               : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
-  int stage_cap = quad ? q_stage_entries(tile_bytes) : STAGE_ENTRIES;
+  int stage_cap = quad ? q_stage_bytes(tile_bytes) / (int)sizeof(E) - WAVE : STAGE_ENTRIES;
   int64_t nrb = (op_rows + block_rows - 1) / block_rows;
   int nsplit = 1;
   if (nrb >= 192) {
@@ -1217,11 +1361,11 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   if (quad && !transposed && !rows_tile_major && allow_big_tile && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
     const int tcb = Q_TILE_BYTES_BIG / (ldp * 4);
     const double est = 1.3 * (double)S.nnz / ((double)nrb * std::ceil((double)op_cols / tcb));
-    if (est <= 0.78 * q_stage_entries(Q_TILE_BYTES_BIG)) {
+    if (est <= 0.78 * (q_stage_bytes(Q_TILE_BYTES_BIG) / (int)sizeof(E) - WAVE)) {
       tile_bytes = Q_TILE_BYTES_BIG;
       tc = tcb;
       nct = (int)((op_cols + tc - 1) / tc);
-      stage_cap = q_stage_entries(tile_bytes);
+      stage_cap = q_stage_bytes(tile_bytes) / (int)sizeof(E) - WAVE;
       if (nsplit > 1) nsplit = (int)std::min<int64_t>(nct, nsplit);
     }
   }
@@ -1239,7 +1383,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
       hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(S.rows, 4, 8192)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                          S.ptr, S.idx, S.rows, nct, inv_nct, d_seg);
     } else {
-      build_tile_index(S, tc, nct, d_seg, s);
+      if constexpr (f32) build_tile_index(S, tc, nct, d_seg, s);
     }
   }
   // Rows sorted by length, longest first (quad format built from a CSR): the four rows of a quad and the
@@ -1355,27 +1499,28 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
               (long long)max_chunk, stage_cap, (long long)total);
     if (max_chunk <= stage_cap) break;
     if (tile_bytes == Q_TILE_BYTES_BIG)   // the estimate was too optimistic: take the default split instead of halving the row blocks
-      return build_tiled(S, transposed, ldp, op, buf, s, rows_tile_major, packed_rows, false, seg_ready);
+      return build_tiled_t<VT>(S, transposed, ldp_elems, op, buf, s, rows_tile_major, packed_rows, false, seg_ready);
     if (attempt == 3 || nrb * 2 > op_rows) return false;  // does not fit: the caller stays on the row kernel
     nrb *= 2;
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
   }
-  Ent* d_ent = reinterpret_cast<Ent*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(Ent)));
+  E* d_ent = reinterpret_cast<E*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(E)));
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
-  const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
+  const bool staged_fill = f32 && quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
                            (double)total <= 0.85 * QF_CAP_MAX * ((double)op_rows / 4.0) && nct <= 768;
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : QF_CAP_MAX;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
   if (packed_rows && !runs_fill) return false;
-  if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(Ent), s));
-  else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(Ent), s));
+  if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(E), s));
+  else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(E), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
   uint32_t* run_global = nullptr;
   if (!quad && lds > 48 * 1024) {
     run_global = buf.run.as<uint32_t>((size_t)nrb * waves * nct);
     lds = 0;
   }
+  if constexpr (f32) {
   if (transposed)
     hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
@@ -1393,7 +1538,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                        (size_t)qf_cap * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
                        d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (quad)
-    hipLaunchKernelGGL(quad_fill_kernel, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
+    hipLaunchKernelGGL(quad_fill_kernel<float>, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (slots == 2)
     hipLaunchKernelGGL((tiled_fill_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)(nrb * 16)), dim3(WAVE), lds, s, S.ptr, S.idx, S.val, d_seg,
@@ -1401,12 +1546,26 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
   else
     hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)(nrb * 8)), dim3(WAVE), lds, s, S.ptr, S.idx, S.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
+  } else {
+    (void)lds; (void)run_global; (void)qf_cap; (void)d_rank;
+    hipLaunchKernelGGL(quad_fill_kernel<double>, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
+                       S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+  }
   SAPCA_HIP(hipGetLastError());
-  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp; op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
+  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
   op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   return true;
+}
+}  // namespace
+
+bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s,
+                 bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready) {
+  return build_tiled_t<float>(S, transposed, ldp, op, buf, s, rows_tile_major, packed_rows, allow_big_tile, seg_ready);
+}
+bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s) {
+  return build_tiled_t<double>(S, false, ldp, op, buf, s, false, nullptr, true, false);
 }
 
 void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, int64_t cols, int ldp, TiledBuffers& buf,
@@ -1426,7 +1585,7 @@ int tiled_tile_count(int64_t cols, int ldp) {
 
 void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s) {
-  SAPCA_CHECK(op.valid, SAPCA_ERR_ARG, "tiled sweep: operator not built");
+  SAPCA_CHECK(op.valid && op.elem == 4, SAPCA_ERR_ARG, "tiled sweep: operator not built");
   SAPCA_CHECK(ldx == op.ldp || (op.fmt == 1 && op.ldp == 64 && ldx == 128), SAPCA_ERR_ARG,
               "tiled sweep: panel leading dimension does not match the operator's tile geometry");
   static const int mode = getenv("SAPCA_TILED_MODE") ? atoi(getenv("SAPCA_TILED_MODE")) : 0;  // ablation switches (debug)
@@ -1468,9 +1627,32 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
     }
     if (op.nsplit > 1) {
       const int64_t total = op.rows * (int64_t)op.ldp;
-      hipLaunchKernelGGL(split_reduce_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
+      hipLaunchKernelGGL(split_reduce_kernel<float>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
                          op.ldp, ncp, cv, Y + c0, ldy);
     }
+  }
+  SAPCA_HIP(hipGetLastError());
+}
+
+void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
+                hipStream_t s) {
+  SAPCA_CHECK(op.valid && op.elem == 8 && op.fmt == 1, SAPCA_ERR_ARG, "tiled sweep: no f64 operator built");
+  SAPCA_CHECK(ldx == op.ldp, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension does not match the operator's tile geometry");
+  double* out = Y;
+  int ldo = ldy, nc = ncols;
+  double* part = nullptr;
+  if (op.nsplit > 1) {
+    part = scratch.as<double>((size_t)op.nsplit * op.rows * op.ldp);
+    out = part;
+    ldo = op.ldp;
+    nc = op.ldp;
+  }
+  if (op.tile_bytes == Q_TILE_BYTES_BIG) launch_quad_f64<Q_TILE_BYTES_BIG>(op, X, ldx, out, ldo, nc, cvec, s);
+  else launch_quad_f64<Q_TILE_BYTES>(op, X, ldx, out, ldo, nc, cvec, s);
+  if (op.nsplit > 1) {
+    const int64_t total = op.rows * (int64_t)op.ldp;
+    hipLaunchKernelGGL(split_reduce_kernel<double>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
+                       op.ldp, ncols, cvec, Y, ldy);
   }
   SAPCA_HIP(hipGetLastError());
 }

@@ -553,6 +553,51 @@ def test_spmm_tiled_matches_row_kernel(session, session_tiled, shape, dens, l):
         np.testing.assert_allclose(a2, want, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize("l", [8, 30, 64])
+def test_g3_spmm_tiled_f64(golden, session_tiled, l):
+    """the staged sweep with f64 values and panels (512-byte panel rows), golden sweeps to f64 rounding"""
+    g = golden("g3_spmm.npz")
+    ptr, idx, val = g["indptr"], g["indices"], g["data"].astype(np.float64)
+    m, n, mu = int(g["m"]), int(g["n"]), g["mu"].astype(np.float64)
+    X, Yin = g[f"X{l}"].astype(np.float64), g[f"Yin{l}"].astype(np.float64)
+    s = session_tiled
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, X), g[f"AX{l}"], atol=1e-10)
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, X, mu), g[f"AcX{l}"], atol=1e-10)
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, Yin, None, transposed=True), g[f"AtY{l}"], atol=1e-10)
+    np.testing.assert_allclose(s.spmm(ptr, idx, val, m, n, Yin, mu, transposed=True), g[f"ActY{l}"], atol=1e-10)
+
+
+@pytest.mark.parametrize("shape,dens,l", [((5000, 3000), 0.02, 60), ((3000, 40000), 0.004, 33), ((70000, 900), 0.01, 20),
+                                          ((1027, 333), 0.1, 7), ((1000, 1000), 0.0, 16)])
+def test_spmm_tiled_f64_matches_row_kernel(session, session_tiled, shape, dens, l):
+    m, n = shape
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, dens, seed=8, dtype=torch.float64))
+    X = synth.gaussian_panel(n, l, 3).numpy()
+    Yin = synth.gaussian_panel(m, l, 4).numpy()
+    a1, a2 = session.spmm(ptr, idx, val, m, n, X), session_tiled.spmm(ptr, idx, val, m, n, X)
+    np.testing.assert_allclose(a2, a1, atol=1e-11 * max(1.0, float(np.abs(a1).max())))
+    b1 = session.spmm(ptr, idx, val, m, n, Yin, None, transposed=True)
+    b2 = session_tiled.spmm(ptr, idx, val, m, n, Yin, None, transposed=True)
+    np.testing.assert_allclose(b2, b1, atol=1e-11 * max(1.0, float(np.abs(b1).max())))
+    if dens > 0:
+        np.testing.assert_allclose(a2, mat(ptr, idx, val, m, n) @ X, atol=1e-10 * max(1.0, float(np.abs(a1).max())))
+
+
+def test_f64_fit_through_the_staged_sweep(golden):
+    """G4 in f64 with the staged sweep forced on: the oracle's numbers to 1e-10, like the row kernel"""
+    g = golden("g4_randomized_fit.npz")
+    m, n, k, p, q = (int(g[x]) for x in "mnkpq")
+    A = mat(g["indptr"], g["indices"], g["data"].astype(np.float64), m, n)
+    res = []
+    for variant in (1, 2):
+        pca = _builder(k, p, q).spmm_variant(variant).build().set_omega(g["omega"])
+        t = pca.fit_transform(A)
+        np.testing.assert_allclose(pca.singular_values_(np.float64), g["s"], rtol=1e-10)
+        assert O.subspace_angle(pca.components_(np.float64), g["vt"]) < 1e-9
+        res.append(t)
+    np.testing.assert_allclose(res[1], res[0], atol=1e-9 * np.abs(res[0]).max())
+
+
 def test_fit_is_the_same_with_either_sweep_kernel(golden):
     g = golden("g4_randomized_fit.npz")
     m, n, k, p, q = (int(g[x]) for x in "mnkpq")
