@@ -348,8 +348,7 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
     CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
     hipStream_t s = h->stream;
     // spmm_variant == 2 exercises the LDS-staged sweep on its own (f32 only): panels padded to 64/128
-    bool want_tiled = h->opt.spmm_variant == 2;
-    if (sizeof(T) == 8 && l > 64) want_tiled = false;   // f64: staged sweep for panels of up to 64 columns
+    const bool want_tiled = h->opt.spmm_variant == 2;
     const int ld = want_tiled ? (l <= 64 ? 64 : 128) : (int)sapca::round_up((int64_t)l, 16);
     const uint64_t in_rows = transposed ? m : n, out_rows = transposed ? n : m;
     T* stage = h->scratch2.as<T>(std::max<uint64_t>(in_rows * l, out_rows * l) + n + 2 * 128);

@@ -95,8 +95,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
     const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
     const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
-    const int64_t l_max = sizeof(T) == 4 ? 128 : 64;   // f64: one geometry, panels of up to 64 columns
-    if (l >= 1 && l <= l_max && n_kept > 0) {
+    if (l >= 1 && l <= 128 && n_kept > 0) {
       const int ldp = sizeof(T) == 4 ? k::tiled_geometry((int)l) : 64;
       const double row_bytes = (double)ldp * sizeof(T);
       const double tile_bytes = 80.0 * 1024.0, block_rows = row_bytes == 256.0 ? 512.0 : 256.0;

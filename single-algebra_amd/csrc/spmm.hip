@@ -148,8 +148,8 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
       return;
     }
   } else {
-    // f64: the staged sweep exists for panels of 64 columns (512-byte rows)
-    if (variant != 1 && tiled && tiled->valid && tiled->elem == 8 && tiled->ldp == ldx && tiled->rows == A.rows &&
+    // f64: 64-column tile geometry (512-byte rows), 128-column panels in two passes
+    if (variant != 1 && tiled && tiled->valid && tiled->elem == 8 && (tiled->ldp == ldx || 2 * tiled->ldp == ldx) && tiled->rows == A.rows &&
         tiled->cols == A.cols) {
       spmm_tiled(*tiled, reinterpret_cast<const double*>(X), ldx, reinterpret_cast<double*>(Y), ldy, ncols,
                  reinterpret_cast<const double*>(cvec), scratch, s);

@@ -1637,22 +1637,30 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
 void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
                 hipStream_t s) {
   SAPCA_CHECK(op.valid && op.elem == 8 && op.fmt == 1, SAPCA_ERR_ARG, "tiled sweep: no f64 operator built");
-  SAPCA_CHECK(ldx == op.ldp, SAPCA_ERR_ARG, "tiled sweep: panel leading dimension does not match the operator's tile geometry");
-  double* out = Y;
-  int ldo = ldy, nc = ncols;
-  double* part = nullptr;
-  if (op.nsplit > 1) {
-    part = scratch.as<double>((size_t)op.nsplit * op.rows * op.ldp);
-    out = part;
-    ldo = op.ldp;
-    nc = op.ldp;
-  }
-  if (op.tile_bytes == Q_TILE_BYTES_BIG) launch_quad_f64<Q_TILE_BYTES_BIG>(op, X, ldx, out, ldo, nc, cvec, s);
-  else launch_quad_f64<Q_TILE_BYTES>(op, X, ldx, out, ldo, nc, cvec, s);
-  if (op.nsplit > 1) {
-    const int64_t total = op.rows * (int64_t)op.ldp;
-    hipLaunchKernelGGL(split_reduce_kernel<double>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
-                       op.ldp, ncols, cvec, Y, ldy);
+  SAPCA_CHECK(ldx == op.ldp || ldx == 2 * op.ldp, SAPCA_ERR_ARG,
+              "tiled sweep: panel leading dimension does not match the operator's tile geometry");
+  double* part = op.nsplit > 1 ? scratch.as<double>((size_t)op.nsplit * op.rows * op.ldp) : nullptr;
+  const int passes = ldx / op.ldp;   // 128-column f64 panels: two column passes, as for f32
+  for (int pass = 0; pass < passes; ++pass) {
+    const int c0 = pass * op.ldp;
+    if (c0 >= ncols && pass > 0) break;
+    const double* Xp = X + c0;
+    const double* cv = cvec ? cvec + c0 : nullptr;
+    const int ncp = std::min(ncols - c0, op.ldp);
+    double* out = Y + c0;
+    int ldo = ldy, nc = ncp;
+    if (op.nsplit > 1) {
+      out = part;
+      ldo = op.ldp;
+      nc = op.ldp;
+    }
+    if (op.tile_bytes == Q_TILE_BYTES_BIG) launch_quad_f64<Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, s);
+    else launch_quad_f64<Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, s);
+    if (op.nsplit > 1) {
+      const int64_t total = op.rows * (int64_t)op.ldp;
+      hipLaunchKernelGGL(split_reduce_kernel<double>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
+                         op.ldp, ncp, cv, Y + c0, ldy);
+    }
   }
   SAPCA_HIP(hipGetLastError());
 }

@@ -568,7 +568,8 @@ def test_g3_spmm_tiled_f64(golden, session_tiled, l):
 
 
 @pytest.mark.parametrize("shape,dens,l", [((5000, 3000), 0.02, 60), ((3000, 40000), 0.004, 33), ((70000, 900), 0.01, 20),
-                                          ((1027, 333), 0.1, 7), ((1000, 1000), 0.0, 16)])
+                                          ((1027, 333), 0.1, 7), ((1000, 1000), 0.0, 16), ((700, 300), 0.05, 110),
+                                          ((40000, 900), 0.02, 100)])
 def test_spmm_tiled_f64_matches_row_kernel(session, session_tiled, shape, dens, l):
     m, n = shape
     ptr, idx, val = csr_np(synth.flat_csr(m, n, dens, seed=8, dtype=torch.float64))
@@ -645,6 +646,21 @@ def test_wide_panel_fit_transform_two_column_passes():
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=2e-4)
     # the leading, well separated components project the same way with either kernel
     np.testing.assert_allclose(res[1][1][:, :12], res[0][1][:, :12], atol=2e-3 * np.abs(res[0][1][:, :12]).max())
+
+
+def test_f64_wide_panel_fit_through_the_staged_sweep():
+    """l = 100 in f64: two 64-column passes over 512-byte-row tiles, fit and projection (k = 90), against the oracle"""
+    m, n, k, p, q = 3000, 400, 90, 10, 2
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, 0.08, seed=31, dtype=torch.float64))
+    om = synth.gaussian_panel(n, k + p, 9).numpy()
+    want = O.fit(ptr, idx, val, m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    res = []
+    for variant in (1, 2):
+        pca = _builder(k, p, q).spmm_variant(variant).build().set_omega(om)
+        t = pca.fit_transform(mat(ptr, idx, val, m, n))
+        np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=1e-9)
+        res.append(t)
+    np.testing.assert_allclose(res[1], res[0], atol=1e-8 * np.abs(res[0]).max())
 
 
 def test_panel_width_limit_is_an_error():
