@@ -101,11 +101,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       const double tile_bytes = 80.0 * 1024.0, block_rows = row_bytes == 256.0 ? 512.0 : 256.0;
       const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_kept * row_bytes / tile_bytes);
       // f64: the row kernel gathers 512 bytes per entry, the staged sweep pays off a little earlier (200k x 20k at
-      // 3 %: 67 tile bytes per entry, 5.4 -> 1.9 ms per sweep).  Small operators stay on the row kernel: below a few
-      // million entries the format build and the per-workgroup tile refills cost more than the gather (10k x 2k at 5 %:
-      // 1.2 ms per fit_transform with the row kernel, 1.7 ms staged).
+      // 3 %: 67 tile bytes per entry, 5.4 -> 1.9 ms per sweep).  Small operators stay on the row kernel: their panels
+      // sit in L2 / Infinity Cache and the format build and per-workgroup tile refills cost more than the gather
+      // (tools/crossover.py, k = 50: f32 ties at 1e7 entries and the staged path wins by 18 % at 1.6e7; f64 wins by
+      // 27 % at 1e7 and loses at 1e6).
       const double entries = (double)nnz * ((double)n_kept / (double)n);
-      const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes && entries >= 4e6;
+      const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes &&
+                                entries >= (sizeof(T) == 4 ? 1e7 : 5e6);
       if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
     }
   }
