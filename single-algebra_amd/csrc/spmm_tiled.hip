@@ -523,15 +523,18 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 // (very long rows) take the direct route and zero their padding themselves, so the entry buffer
 // needs no memset on this path.
 constexpr int QF_CAP_MIN = 4096, QF_CAP_MAX = 6144;   // entries of one quad staged in LDS: 32 KiB (more workgroups per CU) .. 48 KiB
+template <typename VT>
 __global__ void __launch_bounds__(256)
-quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const VT* __restrict__ val,
                         const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
                         const uint32_t* __restrict__ perm, int nct, int cap, float inv_nct,
                         int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
-                        Ent* __restrict__ ent) {
+                        typename EntOf<VT>::type* __restrict__ ent) {
+  typedef typename EntOf<VT>::type E;
+  constexpr int EW = (int)sizeof(E) / 4;   // entry size in LDS words
   extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
-  Ent* stage = reinterpret_cast<Ent*>(qf_lds);     // [cap]
-  uint32_t* lofs = qf_lds + 2 * cap;               // [nct + 1] start of every tile's segment in the image
+  E* stage = reinterpret_cast<E*>(qf_lds);         // [cap]
+  uint32_t* lofs = qf_lds + EW * cap;               // [nct + 1] start of every tile's segment in the image
   uint32_t* cnt_all = lofs + nct + 1;              // [4][nct] entries of row g seen so far in tile t
   const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
@@ -576,21 +579,21 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   const bool staged = total <= (uint32_t)cap;
   if (staged) {
     uint64_t* z = reinterpret_cast<uint64_t*>(stage);
-    for (uint32_t i = threadIdx.x; i < total; i += 256) z[i] = 0;
+    for (uint32_t i = threadIdx.x; i < total * (EW / 2); i += 256) z[i] = 0;
   } else {
     // direct route: zero the padding slots of this wave's row in global memory
     if (wave < qrows) {
       const int32_t* sg = seg + rowof[wave] * (nct + 1);
       for (int t = lane; t < nct; t += WAVE) {
         const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
-        Ent* dst = ent + coff[t] + qoff[t];
-        for (uint32_t k = (uint32_t)(sg[t + 1] - sg[t]); k < steps; ++k) dst[k * 4u + wave] = Ent{0u, 0.f};
+        E* dst = ent + coff[t] + qoff[t];
+        for (uint32_t k = (uint32_t)(sg[t + 1] - sg[t]); k < steps; ++k) dst[k * 4u + wave] = E();
       }
     } else {
       for (int t = lane; t < nct; t += WAVE) {   // rows past the end of the block: all padding
         const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
-        Ent* dst = ent + coff[t] + qoff[t];
-        for (uint32_t k = 0; k < steps; ++k) dst[k * 4u + wave] = Ent{0u, 0.f};
+        E* dst = ent + coff[t] + qoff[t];
+        for (uint32_t k = 0; k < steps; ++k) dst[k * 4u + wave] = E();
       }
     }
   }
@@ -604,19 +607,19 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
     // 8 batches are loaded ahead so that one memory round trip serves 512 entries
     for (int64_t eb = e0; eb < e1; eb += 8 * WAVE) {
       int c[8];
-      float v[8];
+      VT v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t e = eb + u * WAVE + lane;
         c[u] = e < e1 ? idx[e] : -1;
-        v[u] = e < e1 ? val[e] : 0.f;
+        v[u] = e < e1 ? val[e] : (VT)0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (c[u] >= 0) {
           int i, t;
           divmod_small(c[u], nct, inv_nct, i, t);
-          Ent x;
+          E x = E();
           x.off = (uint32_t)i * (uint32_t)ldp_bytes;
           x.val = v[u];
           const uint32_t k = atomicAdd(&cnt[t], 1u);
@@ -631,7 +634,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   __syncthreads();
   for (int t = wave; t < nct; t += 4) {
     const uint32_t lo = lofs[t], n = lofs[t + 1] - lo;
-    Ent* dst = ent + coff[t] + qoff[t];
+    E* dst = ent + coff[t] + qoff[t];
     for (uint32_t j = lane; j < n; j += WAVE) dst[j] = stage[lo + j];
   }
 }
@@ -1507,9 +1510,11 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   E* d_ent = reinterpret_cast<E*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(E)));
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
-  const bool staged_fill = f32 && quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
-                           (double)total <= 0.85 * QF_CAP_MAX * ((double)op_rows / 4.0) && nct <= 768;
-  const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : QF_CAP_MAX;
+  // f64 entries are 16 bytes: the LDS image holds QF_CAP_MIN of them (64 KiB), two workgroups per CU
+  const int qf_cap_max = f32 ? QF_CAP_MAX : QF_CAP_MIN;
+  const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
+                           (double)total <= 0.85 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;
+  const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
   if (packed_rows && !runs_fill) return false;
   if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(E), s));
@@ -1534,7 +1539,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       hipLaunchKernelGGL(quad_fill_runs_kernel<false>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), 0, s, S.ptr, S.idx, S.val,
                          packed_rows, d_seg, d_blk, d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   } else if (staged_fill)
-    hipLaunchKernelGGL(quad_fill_staged_kernel, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
+    hipLaunchKernelGGL(quad_fill_staged_kernel<float>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)qf_cap * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
                        d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (quad)
@@ -1547,7 +1552,14 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     hipLaunchKernelGGL((tiled_fill_kernel<8, 4>), dim3((unsigned)(nrb * 8)), dim3(WAVE), lds, s, S.ptr, S.idx, S.val, d_seg,
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   } else {
-    (void)lds; (void)run_global; (void)qf_cap; (void)d_rank;
+    (void)lds; (void)run_global; (void)d_rank;
+    if (staged_fill) {
+      const size_t fill_lds = (size_t)qf_cap * sizeof(E) + ((size_t)5 * nct + 1) * sizeof(uint32_t);
+      static LdsAttrState attr;
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&quad_fill_staged_kernel<double>), fill_lds, attr);
+      hipLaunchKernelGGL(quad_fill_staged_kernel<double>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), fill_lds, s, S.ptr, S.idx,
+                         S.val, d_seg, d_blk, d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+    } else
     hipLaunchKernelGGL(quad_fill_kernel<double>, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   }
