@@ -1,4 +1,4 @@
-// LDS-staged sparse x dense-panel sweep (f32) and the tile-major operator formats it reads.
+// LDS-staged sparse x dense-panel sweep (f32; f64 in the quad formulation) and the tile-major operator formats it reads.
 //
 // Why: per stored entry the sweep reads 8 B of A but a whole panel row (256 B at l = 60).  Served
 // from L2 that gather caps the sweep far below the HBM roofline (measured 5.8 % with
@@ -19,6 +19,9 @@
 //    wave take two consecutive entries of ONE row per step (ds_read_b64), accumulators duplicated in the
 //    two halves and summed at the end.  1.47 ms per C2 sweep against 0.89 ms for the quad kernel; kept
 //    for A/B runs and because its ablation switches (SAPCA_ABL) document how the numbers were obtained.
+//
+//    Panels wider than 64 columns take two column passes over the same format (spmm_tiled); f64 values and
+//    panels use the same format with 16-byte entries and 512-byte panel rows (spmm_quad_f64_kernel).
 //
 // Common to both: an entry is {u32 byte offset of its panel row inside the LDS tile, f32 value}; per
 // column tile the workgroup does  barrier; panel tile + the block's entry chunk -> LDS (both prefetched
