@@ -106,8 +106,9 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       // (tools/crossover.py, k = 50: f32 ties at 1e7 entries and the staged path wins by 18 % at 1.6e7; f64 wins by
       // 27 % at 1e7 and loses at 1e6).
       const double entries = (double)nnz * ((double)n_kept / (double)n);
-      const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes &&
-                                entries >= (sizeof(T) == 4 ? 1e7 : 5e6);
+      double floor_entries = sizeof(T) == 4 ? 1e7 : 5e6;
+      if (const char* e = getenv("SAPCA_TILED_MIN_ENTRIES")) floor_entries = atof(e);   // tests: shards either side of the floor
+      const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes && entries >= floor_entries;
       if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
     }
   }
@@ -311,7 +312,11 @@ void Engine<T>::fit_randomized(H& h) {
   const int l = (int)std::min<int64_t>(l_req, std::min<int64_t>((int64_t)h.m_global, n_used));
   SAPCA_CHECK(l <= 128, SAPCA_ERR_ARG, "n_components + n_oversamples above 128 is not supported");
   const bool tiled = h.tiled_a.valid && h.tiled_at.valid;
-  const int ld = tiled ? std::max(h.tiled_a.ldp, l <= 64 ? 64 : 128) : (int)round_up(l, 16);
+  // The panel leading dimension enters the element counts of the all-reduces below, so with more than one rank it must
+  // not depend on anything a rank decides locally (its own entry count against the staged-sweep floor, whether its
+  // format build succeeded): row-sharded fits always use the staged sweep's panel geometry, whichever kernel a rank
+  // picks for its shard (the row kernel takes any multiple of 16).
+  const int ld = (tiled || h.comm.active()) ? std::max(tiled ? h.tiled_a.ldp : 0, l <= 64 ? 64 : 128) : (int)round_up(l, 16);
   const int q = (int)h.opt.n_power_iterations;
   const int norm = h.opt.normalizer;
   const bool center = h.opt.center != 0;
