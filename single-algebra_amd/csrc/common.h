@@ -122,6 +122,7 @@ struct TiledOp {
   int elem = 4;             // bytes per value and panel element: 4 (f32) or 8 (f64)
   int tc = 0, nct = 0;      // panel rows per column tile, number of tiles
   int nrb = 0;              // row blocks (one workgroup each)
+  int block_rows = 0;       // most rows a block holds (quad format: 256 f64, 512, or 1024 for the DPP-fed sweep with 16 row slots)
   int nsplit = 1, tiles_per_split = 0;
   int slots = 2;            // lane groups per wave the entry stream was padded for
   int fmt = 0;              // 0: two half-waves share a row; 1: "quad", one row per 16-lane group
@@ -132,9 +133,14 @@ struct TiledOp {
   const uint32_t* wave_off = nullptr;  // [nrb*nct][8]
   const uint8_t* steps = nullptr;      // [nrb*nct][256]
   const void* ent = nullptr;           // {u32 lds byte offset, f32 value} or {u32 offset, u32 pad, f64 value}
+  // DPP-fed sweep (spmm_dq.hip): per (row block, wave, tile) {entry offset / 8, 16-step chunks}, and one byte per
+  // two steps (4 x row slot of the wave; placed at 8 * (entry offset / 64 + (chunk * 16 + wave)))
+  bool dq = false;
+  const uint8_t* dq_desc = nullptr;
+  const uint32_t* dq_info = nullptr;
 };
 struct TiledBuffers {
-  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens;
+  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens, dq_desc, dq_info;
 };
 
 struct Stream {

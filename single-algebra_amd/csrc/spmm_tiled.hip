@@ -34,6 +34,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "kernels.h"
+#include "spmm_dq.h"
 
 namespace sapca {
 namespace k {
@@ -373,8 +374,13 @@ constexpr int Q_MAX_TILES_RUNS = 16384;          // tile-major builder (bounded 
 constexpr int Q_TILE_BYTES_BIG = 96 * 1024;      // for operators whose chunks leave room: fewer, longer tile steps
 constexpr int q_stage_bytes(int tile_bytes) { return LDS_TOTAL - tile_bytes - 1024; }
 constexpr int q_stage_entries(int tile_bytes) { return q_stage_bytes(tile_bytes) / 8 - WAVE; }
-constexpr int Q_BLOCK_QUADS = BLOCK_ROWS / 4;   // stride of the per-chunk quad step table
+constexpr int QBLOCK_ROWS = 1024;                // most rows of a quad-format block (the DPP-fed sweep with 16 row slots per lane group)
+constexpr int Q_BLOCK_QUADS = QBLOCK_ROWS / 4;   // stride of the per-chunk quad step table
+constexpr int ENT_SLACK = 4 * WAVE;             // zero entries behind the last chunk: the sweeps read whole 16-step chunks (and three ahead)
 constexpr int q_rows_per_group(int ldp) { return (ldp == 64 ? 128 : 64) / QWAVES; }
+// steps of a quad in a tile: its longest row segment, rounded up to an even count (the DPP-fed sweep of spmm_dq.hip
+// switches row slots every two steps)
+__host__ __device__ inline int q_steps(int longest) { return (longest + 1) & ~1; }
 // quads (4 consecutive rows) of a block are dealt to its 16 waves in contiguous, balanced ranges
 __host__ __device__ inline int q_first(int wave, int nquads) { return wave * nquads / QWAVES; }
 
@@ -427,11 +433,11 @@ tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 
 // one block per (row block, column tile): steps of every quad (= its longest row segment), entry
 // offset of every wave, chunk size
-__global__ void __launch_bounds__(BLOCK_ROWS)
+__global__ void __launch_bounds__(QBLOCK_ROWS)
 quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm,
                   int nct, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
                   int64_t* __restrict__ chunk_size) {
-  __shared__ uint32_t scan[BLOCK_ROWS];
+  __shared__ uint32_t scan[QBLOCK_ROWS];
   const int rb = blockIdx.x / nct, ct = blockIdx.x % nct;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
@@ -442,12 +448,12 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
     len = seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
   }
   int qmax = max(len, __shfl_xor(len, 1));
-  qmax = max(qmax, __shfl_xor(qmax, 2));
+  qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
   const uint32_t padded = (lr & 3) == 0 ? (uint32_t)qmax * 4u : 0u;
   if ((lr & 3) == 0) steps[(int64_t)blockIdx.x * Q_BLOCK_QUADS + lr / 4] = (uint16_t)qmax;
   scan[lr] = padded;
   __syncthreads();
-  for (int off = 1; off < BLOCK_ROWS; off <<= 1) {
+  for (int off = 1; off < QBLOCK_ROWS; off <<= 1) {
     uint32_t v = lr >= off ? scan[lr - off] : 0;
     __syncthreads();
     scan[lr] += v;
@@ -459,7 +465,7 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
     const int first_row = 4 * q_first(lr, nquads);
     wave_off[(int64_t)blockIdx.x * QWAVES + lr] = first_row > 0 ? scan[first_row - 1] : 0u;
   }
-  if (lr == BLOCK_ROWS - 1) chunk_size[blockIdx.x] = scan[lr];
+  if (lr == QBLOCK_ROWS - 1) chunk_size[blockIdx.x] = scan[lr];
 }
 
 // one wave per row: the k-th entry (in column order) that the row has in tile t goes to slot
@@ -557,7 +563,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
       const int32_t* sg = seg + rowof[g] * (nct + 1);
       mx = max(mx, sg[t + 1] - sg[t]);
     }
-    lofs[t + 1] = (uint32_t)mx * 4u;
+    lofs[t + 1] = (uint32_t)q_steps(mx) * 4u;
     for (int g = 0; g < 4; ++g) cnt_all[g * nct + t] = 0;
   }
   if (threadIdx.x == 0) lofs[0] = 0;
@@ -799,7 +805,7 @@ quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
       }
     }
     int qmax = max(len, __shfl_xor(len, 1));
-    qmax = max(qmax, __shfl_xor(qmax, 2));
+    qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
     for (int k = k0; k < qmax; k += 16) {
       Ent x{0u, 0.f};
       if (k < len) {
@@ -881,9 +887,9 @@ tquad_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
                    uint16_t* __restrict__ rank, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off,
                    uint32_t* __restrict__ wave_off, int64_t* __restrict__ chunk_size) {
   extern __shared__ uint32_t tq_lds[];
-  uint32_t* mask = tq_lds;                                   // [BLOCK_ROWS][maskw]
-  uint32_t* pre = tq_lds + (size_t)BLOCK_ROWS * maskw;       // [BLOCK_ROWS][maskw]: set bits in the words before
-  __shared__ uint32_t wsum[BLOCK_ROWS / WAVE];
+  uint32_t* mask = tq_lds;                                   // [QBLOCK_ROWS][maskw]
+  uint32_t* pre = tq_lds + (size_t)QBLOCK_ROWS * maskw;       // [QBLOCK_ROWS][maskw]: set bits in the words before
+  __shared__ uint32_t wsum[QBLOCK_ROWS / WAVE];
   __shared__ uint32_t qex[Q_BLOCK_QUADS];
   // launch order: all column blocks of one tile are neighbours, so the source rows they share
   // (and the segb lines) are fetched from HBM once and then hit in L2 / Infinity Cache
@@ -895,7 +901,7 @@ tquad_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
   const int grp = threadIdx.x / 16, gl = threadIdx.x & 15;
   int64_t e0[TQ_NI], e1[TQ_NI];
   tquad_runs(e0, e1, ptr, segb, nb, b, t, nct, nr);
-  for (int i = threadIdx.x; i < BLOCK_ROWS * maskw; i += TQ_THREADS) mask[i] = 0;
+  for (int i = threadIdx.x; i < QBLOCK_ROWS * maskw; i += TQ_THREADS) mask[i] = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < TQ_NI; ++j) {
@@ -914,9 +920,9 @@ tquad_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
   // steps of every quad, exclusive scan of the padded quad sizes (wave scans + 8 wave totals)
   uint32_t padded = 0, incl = 0;
   const int lane = lr & (WAVE - 1), wv = lr / WAVE;
-  if (lr < BLOCK_ROWS) {
+  if (lr < QBLOCK_ROWS) {
     int qmax = max(len, __shfl_xor(len, 1));
-    qmax = max(qmax, __shfl_xor(qmax, 2));
+    qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
     padded = (lr & 3) == 0 ? (uint32_t)qmax * 4u : 0u;
     if ((lr & 3) == 0) steps[chunk * Q_BLOCK_QUADS + lr / 4] = (uint16_t)qmax;
     incl = padded;
@@ -928,7 +934,7 @@ tquad_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
     if (lane == WAVE - 1) wsum[wv] = incl;
   }
   __syncthreads();
-  if (lr < BLOCK_ROWS) {
+  if (lr < QBLOCK_ROWS) {
     uint32_t before = 0;
     for (int w = 0; w < wv; ++w) before += wsum[w];
     incl += before;
@@ -936,7 +942,7 @@ tquad_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
       quad_off[chunk * Q_BLOCK_QUADS + lr / 4] = incl - padded;
       qex[lr / 4] = incl - padded;
     }
-    if (lr == BLOCK_ROWS - 1) chunk_size[chunk] = incl;
+    if (lr == QBLOCK_ROWS - 1) chunk_size[chunk] = incl;
   }
   __syncthreads();
   if (lr < QWAVES) wave_off[chunk * QWAVES + lr] = qex[q_first(lr, nquads)];
@@ -1347,8 +1353,14 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
   const int slots = (ldp == 64 && slots_env == 4) ? 4 : 2;
   const int waves = quad ? QWAVES : waves_for(slots);
-  const int block_rows = quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
-                              : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
+  // (the DPP-fed sweep double-buffers the default 80 KiB tile and holds 8 or 16 row slots per lane group: f32 operators
+  // with 64-column tiles keep that split, and take 1024-row blocks -- half the tile refills and barriers per entry --
+  // when that still leaves a row block for most CUs)
+  const bool dq_candidate = f32 && quad && ldp == 64 && getenv("SAPCA_NO_DQ") == nullptr;
+  static const int dq_rows_env = getenv("SAPCA_DQ_BLOCK_ROWS") ? atoi(getenv("SAPCA_DQ_BLOCK_ROWS")) : 0;
+  const int block_rows = dq_candidate ? (dq_rows_env == 512 || dq_rows_env == 1024 ? dq_rows_env : (op_rows >= 1024 * 192 ? 1024 : 512))
+                         : quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
+                                : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
   int stage_cap = quad ? q_stage_bytes(tile_bytes) / (int)sizeof(E) - WAVE : STAGE_ENTRIES;
   int64_t nrb = (op_rows + block_rows - 1) / block_rows;
   int nsplit = 1;
@@ -1364,7 +1376,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // the bigger tile (fewer, longer tile steps, less quad padding) when the chunks are expected to leave room
   // in the smaller staging area; operators fed by the tile-major transposition keep the default split
   // (their tile count is fixed before the transposition runs)
-  if (quad && !transposed && !rows_tile_major && allow_big_tile && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
+  if (quad && !transposed && !rows_tile_major && allow_big_tile && !dq_candidate && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
     const int tcb = Q_TILE_BYTES_BIG / (ldp * 4);
     const double est = 1.3 * (double)S.nnz / ((double)nrb * std::ceil((double)op_cols / tcb));
     if (est <= 0.78 * (q_stage_bytes(Q_TILE_BYTES_BIG) / (int)sizeof(E) - WAVE)) {
@@ -1460,7 +1472,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     }
     nchunks = nrb * nct;
     d_blk = buf.blk.as<int32_t>((size_t)nrb + 1);
-    d_steps = buf.steps.as<uint8_t>((size_t)nchunks * BLOCK_ROWS);
+    d_steps = buf.steps.as<uint8_t>((size_t)nchunks * (quad ? (size_t)Q_BLOCK_QUADS * 2 : (size_t)BLOCK_ROWS));
     d_wave_off = buf.wave_off.as<uint32_t>((size_t)nchunks * waves);
     if (quad) d_quad_off = buf.run.as<uint32_t>((size_t)nchunks * Q_BLOCK_QUADS);
     d_chunk = buf.chunk_off.as<int64_t>((size_t)nchunks + 1);
@@ -1470,11 +1482,13 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       hipLaunchKernelGGL(bound_index_kernel, dim3(grid_for(S.rows * (nrb + 1), 256, 16384)), dim3(256), 0, s, S.ptr, S.idx,
                          S.rows, d_blk, (int)nrb, d_seg);
       d_rank = buf.rank.as<uint16_t>((size_t)S.nnz);
+      static LdsAttrState tq_attr;
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&tquad_count_kernel), (size_t)2 * QBLOCK_ROWS * maskw * sizeof(uint32_t), tq_attr);
       hipLaunchKernelGGL(tquad_count_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS),
-                         (size_t)2 * BLOCK_ROWS * maskw * sizeof(uint32_t), s, S.ptr, S.idx, d_seg, S.rows, d_blk, (int)nrb, nct,
+                         (size_t)2 * QBLOCK_ROWS * maskw * sizeof(uint32_t), s, S.ptr, S.idx, d_seg, S.rows, d_blk, (int)nrb, nct,
                          maskw, d_rank, reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     } else if (quad)
-      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(QBLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     else if (slots == 2)
       hipLaunchKernelGGL((tiled_count_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
@@ -1503,14 +1517,14 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       fprintf(stderr, "sapca: build_tiled%s rows %lld cols %lld nrb %lld nct %d split %d max_chunk %lld (cap %d) total %lld\n",
               transposed ? " (transposed source)" : "", (long long)op_rows, (long long)op_cols, (long long)nrb, nct, nsplit,
               (long long)max_chunk, stage_cap, (long long)total);
-    if (max_chunk <= stage_cap) break;
+    if (max_chunk <= stage_cap || (dq_candidate && block_rows > 512)) break;   // 1024-row blocks: no entry staging to fit
     if (tile_bytes == Q_TILE_BYTES_BIG)   // the estimate was too optimistic: take the default split instead of halving the row blocks
       return build_tiled_t<VT>(S, transposed, ldp_elems, op, buf, s, rows_tile_major, packed_rows, false, seg_ready);
     if (attempt == 3 || nrb * 2 > op_rows) return false;  // does not fit: the caller stays on the row kernel
     nrb *= 2;
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
   }
-  E* d_ent = reinterpret_cast<E*>(buf.ent.ensure((size_t)(total + 2 * WAVE) * sizeof(E)));
+  E* d_ent = reinterpret_cast<E*>(buf.ent.ensure((size_t)(total + ENT_SLACK) * sizeof(E)));
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
   // f64 entries are 16 bytes: the LDS image holds QF_CAP_MIN of them (64 KiB), two workgroups per CU
@@ -1520,8 +1534,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
   if (packed_rows && !runs_fill) return false;
-  if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)(2 * WAVE) * sizeof(E), s));
-  else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + 2 * WAVE) * sizeof(E), s));
+  if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)ENT_SLACK * sizeof(E), s));
+  else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + ENT_SLACK) * sizeof(E), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
   uint32_t* run_global = nullptr;
   if (!quad && lds > 48 * 1024) {
@@ -1567,10 +1581,17 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   }
   SAPCA_HIP(hipGetLastError());
-  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb;
+  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
   op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
+  if constexpr (f32) {
+    const bool dq_ok = dq_build_tables(op, buf, s);
+    if (!dq_ok && block_rows > 512) {   // only the DPP-fed sweep reads 1024-row blocks: the caller stays on the row kernel
+      op.valid = false;
+      return false;
+    }
+  }
   return true;
 }
 }  // namespace
@@ -1623,7 +1644,10 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
       ldo = op.ldp;
       nc = op.ldp;
     }
-    if (op.fmt == 1) {
+    static const bool force_staged = getenv("SAPCA_SWEEP_STAGED") != nullptr;   // A/B: the staged-entry quad sweep
+    if (op.fmt == 1 && !force_staged && mode == 0 && dq_usable(op, ldx)) {
+      launch_dq(op, Xp, ldx, out, ldo, nc, cv, s);
+    } else if (op.fmt == 1) {
       const bool big = op.tile_bytes == Q_TILE_BYTES_BIG;
       if (op.ldp == 64 && pf && big) launch_quad<64, true, Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, mode, s);
       else if (op.ldp == 64 && pf) launch_quad<64, true, Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, mode, s);

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Emits single-algebra_amd/csrc/spmm_dq_gen.h: the inline-asm main loop of the DPP-fed quad sweep (spmm_dq.hip).
+
+The kernel around it (C++ prologue and epilogue) is in spmm_dq.hip; this file only writes the part that cannot be
+expressed in HIP C++: accumulators in fixed VGPRs addressed through the VGPR index mode (M0[7:0] = 4 * row slot,
+SRC2 + DST relative), entries broadcast to their 16-lane row group with DPP row_newbcast, the panel tile brought into
+LDS by LDS-DMA (global_load_lds_dwordx4) into two 80 KiB buffers, counted vmcnt / lgkmcnt waits.
+
+Per workgroup (16 waves, one (row block, tile range)):  for every tile t:
+  E0..E2 + descriptor loads of this tile; wait for this wave's LDS-DMA pieces of tile t; s_barrier;
+  LDS-DMA of tile t+1 into the other buffer; L2 prefetch of the next tile's entry stream;
+  chunks of 16 steps: a chunk is one 512-byte coalesced load (lane (g, i) = step i of lane group g), eight groups of
+  two steps each {2 v_add_u32_dpp (address), 2 ds_read_b128, 2 v_mov_b32_dpp (value), 4 v_pk_fma_f32 under the index}.
+
+Run:  python3 tools/gen_spmm_dq.py   (writes the header next to the kernel; the header is committed)
+"""
+import os
+import sys
+
+ACC = 56          # first accumulator register; 4 per row slot, + 4 for the trash slot (steps past the end of a stream)
+RG = 8            # row slots per lane group (rows per wave = 4 * RG): set per variant in main()
+TILE_B = 81920    # bytes of one LDS tile buffer (320 panel rows of 256 bytes)
+EB = [(10, 11), (12, 13), (14, 15)]
+VDESC, VLB, VT, VPF = 16, 17, 18, 19
+A = [[20, 21], [22, 23]]
+B = [24, 26]
+VINFO = (28, 29)
+W = [[32, 36], [40, 44]]
+# scalars
+S_D0, S_D1, S_REM, S_DL = 36, 37, 38, 39
+S_PTR = 40        # s[40:41] entry stream pointer of the current chunk
+S_DP = 42         # s[42:43] scratch pointer (descriptor / prefetch)
+S_T, S_NT, S_CW, S_TABS, S_BUF, S_NCH, S_OFF8 = 44, 45, 46, 47, 48, 49, 50
+S_A, S_B2, S_C, S_D, S_E = 51, 52, 53, 54, 55
+S_INFO = 56       # s[56:57] info pointer of the current 64-tile window
+S_4NCT, S_TLAST, S_DL1 = 58, 59, 60
+
+
+def grp_a(k, e, L):
+    p = k & 1
+    ex, ey = e
+    for t in range(2):
+        L.append(f"v_add_u32_dpp v{A[p][t]}, v{ex}, v{VLB} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+    for t in range(2):
+        L.append(f"ds_read_b128 v[{W[p][t]}:{W[p][t] + 3}], v{A[p][t]}")
+    for t in range(2):
+        L.append(f"v_mov_b32_dpp v{B[p] + t}, v{ey} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+
+
+def grp_b(k, L, wait):
+    p = k & 1
+    sd = S_D0 if k < 4 else S_D1
+    L.append(f"s_waitcnt lgkmcnt({wait})")
+    L.append(f"s_set_gpr_idx_on s{sd}, gpr_idx(SRC2,DST)")
+    for t in range(2):
+        w = W[p][t]
+        sel = "op_sel_hi:[1,0,1]" if t == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        L.append(f"v_pk_fma_f32 v[{ACC}:{ACC + 1}], v[{w}:{w + 1}], v[{B[p]}:{B[p] + 1}], v[{ACC}:{ACC + 1}] {sel}")
+        L.append(f"v_pk_fma_f32 v[{ACC + 2}:{ACC + 3}], v[{w + 2}:{w + 3}], v[{B[p]}:{B[p] + 1}], v[{ACC + 2}:{ACC + 3}] {sel}")
+    L.append("s_set_gpr_idx_off")
+    if k not in (3, 7):
+        L.append(f"s_lshr_b32 s{sd}, s{sd}, 8")
+
+
+def chunk_body(buf, L, lbl):
+    """16 steps from entry buffer `buf`.  On entry the buffer's load has been waited for.  Before the last group's
+    DPP reads are issued nothing may overwrite the buffer; its reload (the chunk three ahead, if the stream has one)
+    is issued right after them."""
+    e = EB[buf]
+    depth = 2
+    L.append(f"s_add_u32 s{S_DL1}, s{S_DL}, 1")
+    L.append(f"v_readlane_b32 s{S_D0}, v{VDESC}, s{S_DL}")
+    L.append(f"v_readlane_b32 s{S_D1}, v{VDESC}, s{S_DL1}")
+    for k in range(depth):
+        grp_a(k, e, L)
+    for k in range(8):
+        ahead = min(depth, 8 - k) - 1
+        grp_b(k, L, 2 * ahead)
+        if k + depth < 8:
+            grp_a(k + depth, e, L)
+            if k + depth == 7:
+                # reload: chunk c + 3 exists  <=>  rem > 3   (rem counts the current chunk)
+                L.append(f"s_cmp_le_u32 s{S_REM}, 3")
+                L.append(f"s_cbranch_scc1 {lbl}_norel")
+                L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536")
+                L.append(f"{lbl}_norel:")
+    L.append(f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200")
+    L.append(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
+    L.append(f"s_add_u32 s{S_DL}, s{S_DL}, 2")
+    L.append(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
+
+
+def dma(L, s_tile, s_bufbase):
+    """this wave's five 1 KiB pieces of tile `s_tile` (absolute index, SGPR number) into the LDS buffer at SGPR s_bufbase"""
+    L.append(f"s_mov_b32 s{S_A}, s{s_tile}")
+    L.append(f"s_add_u32 s{S_B2}, s{s_bufbase}, %[wdma]")
+    for i in range(5):
+        L.append(f"v_add_u32 v{VT}, s{S_A}, %[rowb0]")
+        L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
+        L.append(f"v_mul_lo_u32 v{VT}, v{VT}, %[stride]")
+        L.append(f"v_add_u32 v{VT}, %[col16], v{VT}")
+        L.append(f"s_mov_b32 m0, s{S_B2}")
+        L.append("s_nop 0")
+        L.append(f"global_load_lds_dwordx4 v{VT}, %[X]")
+        if i < 4:
+            L.append(f"s_add_u32 s{S_A}, s{S_A}, s{S_4NCT}")
+            L.append(f"s_add_u32 s{S_B2}, s{S_B2}, 0x400")
+
+
+def ptr_from_off8(L, s_off8, dst, base):
+    """s[dst:dst+1] = base (64-bit operand name) + 64 * s_off8   (s_off8: entry offset in units of 8 entries)"""
+    L.append(f"s_lshl_b32 s{S_C}, s{s_off8}, 6")
+    L.append(f"s_lshr_b32 s{S_D}, s{s_off8}, 26")
+    L.append(f"s_mov_b64 s[{dst}:{dst + 1}], %[{base}]")
+    L.append(f"s_add_u32 s{dst}, s{dst}, s{S_C}")
+    L.append(f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}")
+
+
+def body():
+    L = []
+    nreg = 4 * RG + 4
+    # accumulators and the trash slot <- 0
+    L += [f"s_mov_b32 s{S_A}, 0", f"s_set_gpr_idx_on s{S_A}, gpr_idx(DST)", "1:", f"v_mov_b32 v{ACC}, 0",
+          f"s_add_u32 s{S_A}, s{S_A}, 1", f"s_set_gpr_idx_idx s{S_A}", f"s_cmp_lt_u32 s{S_A}, {nreg}", "s_cbranch_scc1 1b",
+          "s_set_gpr_idx_off"]
+    L += [f"s_mov_b32 s{S_T}, 0", f"s_mov_b32 s{S_NT}, %[ntiles]", f"s_mov_b32 s{S_CW}, %[cw]", f"s_mov_b32 s{S_TABS}, %[t0]",
+          f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], 2",
+          f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1"]
+    # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
+    L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
+    # first tile: synchronous LDS-DMA into buffer 0
+    dma(L, S_TABS, S_BUF)
+    L += ["s_waitcnt vmcnt(0)"]
+    L += ["10:"]   # ---- tile loop
+    # a new 64-tile window of the info table
+    L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"s_cmp_lg_u32 s{S_A}, 0", "s_cbranch_scc1 11f", f"s_cmp_eq_u32 s{S_T}, 0",
+          "s_cbranch_scc1 11f", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
+          f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]", "s_waitcnt vmcnt(0)", "11:"]
+    L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}",
+          f"s_min_u32 s{S_NCH}, s{S_NCH}, 32"]   # the builder guarantees it; a corrupt table must not turn into an endless loop
+    ptr_from_off8(L, S_OFF8, S_PTR, "ent")
+    # descriptor chunk index = off8 / 8 + cw  (8 bytes each)
+    L += [f"s_lshr_b32 s{S_E}, s{S_OFF8}, 3", f"s_add_u32 s{S_E}, s{S_E}, s{S_CW}", f"s_lshl_b32 s{S_C}, s{S_E}, 3", f"s_lshr_b32 s{S_D}, s{S_E}, 29",
+          f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[desc]", f"s_add_u32 s{S_DP}, s{S_DP}, s{S_C}", f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, s{S_D}"]
+    for i, e in enumerate(EB):
+        L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i}")
+    L.append(f"global_load_dword v{VDESC}, %[l4], s[{S_DP}:{S_DP + 1}]")
+    # this wave's pieces of the tile have landed (younger: prefetch, reloads -- long complete -- and the four loads above)
+    L += ["s_waitcnt vmcnt(4)", "s_barrier"]
+    # next tile -> the other buffer (the last tile reloads itself: keeps the wait counts below static)
+    L += [f"s_add_u32 s{S_E}, s{S_TABS}, 1", f"s_min_u32 s{S_E}, s{S_E}, s{S_TLAST}", f"s_sub_u32 s{S_C}, {TILE_B}, s{S_BUF}"]
+    L += [f"s_mov_b32 s{S_D}, s{S_C}"]
+    dma_next = []
+    dma(dma_next, S_E, S_D)
+    L += dma_next
+    # L2 prefetch of the next tile's entry stream (lane * 128 bytes, clamped to the stream)
+    L += [f"s_add_u32 s{S_A}, s{S_T}, 1", f"s_and_b32 s{S_A}, s{S_A}, 63", f"s_add_u32 s{S_C}, s{S_T}, 1",
+          f"s_cmp_lt_u32 s{S_C}, s{S_NT}", "s_cselect_b32 s%d, s%d, 0" % (S_C, S_A),            # window lane of the next tile, or 0
+          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b32 s{S_C}, s{S_T}, s{S_C}",                    # ... lane 0 = a new window (or no next tile): prefetch the current one
+          f"s_and_b32 s{S_C}, s{S_C}, 63",
+          f"v_readlane_b32 s{S_A}, v{VINFO[0]}, s{S_C}", f"v_readlane_b32 s{S_E}, v{VINFO[1]}, s{S_C}"]
+    ptr_from_off8(L, S_A, S_DP, "ent")
+    L += [f"s_lshl_b32 s{S_E}, s{S_E}, 9", f"s_max_u32 s{S_E}, s{S_E}, 4", f"s_sub_u32 s{S_E}, s{S_E}, 4",
+          f"v_min_u32 v{VT}, s{S_E}, %[l128]", f"global_load_dword v{VPF}, v{VT}, s[{S_DP}:{S_DP + 1}]"]
+    L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}", f"s_mov_b32 s{S_DL}, 0"]
+    # peeled chunks 0..2: younger than E0..E2 and the descriptor are the 5 LDS-DMA pieces and the prefetch
+    for i in range(3):
+        L += [f"s_cmp_eq_u32 s{S_REM}, 0", "s_cbranch_scc1 19f"]
+        if i == 0:   # the wait also covers E1, E2 (older than the descriptor): chunks 1 and 2 need none
+            L += ["s_waitcnt vmcnt(6)"]
+        chunk_body(i, L, f"pc{i}")
+    # steady state: chunk c >= 3 from buffer c % 3; its load is followed by those of c + 1, c + 2 where they exist
+    L += ["12:"]
+    for i in range(3):
+        L += [f"s_cmp_eq_u32 s{S_REM}, 0", "s_cbranch_scc1 19f"]
+        L += [f"s_cmp_ge_u32 s{S_REM}, 3", f"s_cbranch_scc1 q{i}_2", f"s_cmp_eq_u32 s{S_REM}, 2", f"s_cbranch_scc1 q{i}_1",
+              "s_waitcnt vmcnt(0)", f"s_branch q{i}_z", f"q{i}_1:", "s_waitcnt vmcnt(1)", f"s_branch q{i}_z", f"q{i}_2:", "s_waitcnt vmcnt(2)", f"q{i}_z:"]
+        chunk_body(i, L, f"sc{i}")
+    L += ["s_branch 12b", "19:"]
+    L += [f"s_add_u32 s{S_T}, s{S_T}, 1", f"s_add_u32 s{S_TABS}, s{S_TABS}, 1", f"s_add_u32 s{S_CW}, s{S_CW}, 16",
+          f"s_sub_u32 s{S_BUF}, {TILE_B}, s{S_BUF}", f"s_cmp_lt_u32 s{S_T}, s{S_NT}", "s_cbranch_scc1 10b"]
+    L += ["s_waitcnt vmcnt(0)"]
+    return L
+
+
+def uniq_labels(L):
+    """inline asm may be emitted more than once per module: named labels get the %= suffix"""
+    import re
+    names = set()
+    for ln in L:
+        m = re.match(r"^([a-z][a-z0-9_]*):$", ln)
+        if m:
+            names.add(m.group(1))
+    out = []
+    for ln in L:
+        for n in sorted(names, key=len, reverse=True):
+            ln = re.sub(rf"\b{n}\b", n + "_%=", ln)
+        out.append(ln)
+    return out
+
+
+def clobbers():
+    v = [f"v{i}" for i in range(10, 48)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 4)]
+    s = [f"s{i}" for i in range(36, 61)]
+    return v + s + ["memory", "scc", "m0"]
+
+
+def main():
+    global RG
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "single-algebra_amd", "csrc", "spmm_dq_gen.h")
+    with open(path, "w") as out:
+        out.write("// generated by tools/gen_spmm_dq.py -- do not edit; the generator documents the structure\n")
+        out.write(f"#define DQ_ACC_BASE {ACC}\n#define DQ_TILE_BYTES {TILE_B}\n")
+        for rg in (8, 16):   # 512-row and 1024-row blocks
+            RG = rg
+            L = uniq_labels(body())
+            out.write(f"#define DQ_MAIN_ASM_{rg} \\\n")
+            for ln in L:
+                out.write(f'  "{ln}\\n" \\\n')
+            out.write("\n")
+            out.write(f"#define DQ_MAIN_CLOBBERS_{rg} " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+            print(f"wrote {path}: RG {rg}, {len(L)} lines")
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,8 @@
 
 constexpr int TILE_ROWS = 320, CHUNKS_PER_BLOCK = 30;
 
-// VAR 0: pk_fma, 8 rows per group   1: v_fma, 8 rows   2: pk_fma, 16 rows
+// VAR 0: pk_fma, 8 rows per group   1: v_fma, 8 rows   2: pk_fma, 16 rows   3: depth 3   4: groups flow across chunks
+// 5: both   6: ablation, no LDS reads   7: ablation, no FMAs (6 and 7 compute nothing meaningful)
 template <int VAR>
 __global__ void __launch_bounds__(1024) k_dq(const float* __restrict__ P, const uint32_t* __restrict__ ent,
                                              const uint32_t* __restrict__ desc, long long wave_stride_bytes,
@@ -53,6 +54,12 @@ __global__ void __launch_bounds__(1024) k_dq(const float* __restrict__ P, const 
   if constexpr (VAR == 0) asm volatile(DQ_ASM_PK8 DQ_OPS : DQ_CLOB_PK8);
   if constexpr (VAR == 1) asm volatile(DQ_ASM_F8 DQ_OPS : DQ_CLOB_F8);
   if constexpr (VAR == 2) asm volatile(DQ_ASM_PK16 DQ_OPS : DQ_CLOB_PK16);
+  if constexpr (VAR == 3) asm volatile(DQ_ASM_PK8D3 DQ_OPS : DQ_CLOB_PK8D3);
+  if constexpr (VAR == 4) asm volatile(DQ_ASM_PK8X DQ_OPS : DQ_CLOB_PK8X);
+  if constexpr (VAR == 5) asm volatile(DQ_ASM_PK8XD3 DQ_OPS : DQ_CLOB_PK8XD3);
+  if constexpr (VAR == 6) asm volatile(DQ_ASM_PK8_NOLDS DQ_OPS : DQ_CLOB_PK8_NOLDS);
+  if constexpr (VAR == 7) asm volatile(DQ_ASM_PK8_NOFMA DQ_OPS : DQ_CLOB_PK8_NOFMA);
+  if constexpr (VAR == 8) asm volatile(DQ_ASM_PK8_ON DQ_OPS : DQ_CLOB_PK8_ON);
 }
 
 static std::vector<float> hP;
@@ -149,10 +156,16 @@ int main() {
   CK(hipMemcpy(dP, hP.data(), hP.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dE, E.data(), E.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dD, D.data(), D.size() * 4, hipMemcpyHostToDevice));
-  for (int threads : {256, 512, 1024}) {
+  for (int threads : {1024}) {
     run<0>("pk_fma  rows/group 8", threads, nblocks, estride, dstride);
     run<1>("v_fma   rows/group 8", threads, nblocks, estride, dstride);
     run<2>("pk_fma  rows/group 16", threads, nblocks, estride, dstride);
+    run<3>("pk_fma  depth 3", threads, nblocks, estride, dstride);
+    run<4>("pk_fma  across chunks", threads, nblocks, estride, dstride);
+    run<5>("pk_fma  across, depth 3", threads, nblocks, estride, dstride);
+    run<6>("ablation: no LDS reads", threads, nblocks, estride, dstride);
+    run<7>("ablation: no FMAs", threads, nblocks, estride, dstride);
+    run<8>("index mode left on", threads, nblocks, estride, dstride);
   }
   return 0;
 }
