@@ -147,6 +147,9 @@ sapca_status sapca_fit_transform_csr_f64(sapca_handle h, uint64_t m, uint64_t n,
 /* Same three operations on HBM-resident CSR (device pointers: int64 row offsets [m+1],
  * int32 column indices [nnz], values [nnz]); `out` is a device buffer m x n_components.
  * The matrix is borrowed: it must stay valid and unmodified until the call returns.
+ * Nothing derived from caller-owned arrays outlives the call: a later sapca_transform_csr_device_*
+ * on the same pointers re-derives what it needs (they may hold different values by then); only
+ * fit_transform, and the library-owned arrays of sapca_upload_csr_*, reuse the fit's preparation.
  * When the handle belongs to a multi-rank communicator (sapca_comm_*), (m, row_offsets, ..)
  * describe THIS rank's row shard and n is the global column count.                            */
 sapca_status sapca_fit_csr_device_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,

@@ -186,7 +186,16 @@ sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t n
   return guarded(h, [&] {
     SAPCA_CHECK(d_out != nullptr || m == 0, SAPCA_ERR_ARG, "null output buffer");
     CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
-    if (fit_first) Engine<T>::fit(*h, A);
+    if (fit_first) {
+      Engine<T>::fit(*h, A);
+    } else if (static_cast<const void*>(v) != h->in_val.p) {
+      // A separate transform call on caller-owned device arrays: pointer identity does not prove the matrix is the fitted
+      // one (values edited in place, an allocator handing the same addresses to another matrix), so the preparation kept
+      // from fit() -- tile-major copy of the values, per-column counts -- is not reused.  It is reused inside
+      // fit_transform (one call, the matrix is borrowed unmodified) and for the library-owned arrays of sapca_upload_csr_*,
+      // which only the library's own entry points modify (each of them drops the preparation).
+      h->prep_key.valid = false;
+    }
     Engine<T>::transform(*h, A, d_out);
   });
 }

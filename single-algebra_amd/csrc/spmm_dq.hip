@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(DQ_THREADS)
 spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct,
                const uint64_t* __restrict__ ent, const uint8_t* __restrict__ desc, const uint32_t* __restrict__ info,
                int64_t panel_rows, const float* __restrict__ X, int ldx, int nsplit, int tiles_per_split,
-               float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec) {
+               float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec, int mode) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
@@ -113,7 +113,7 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
 #define DQ_INPUTS                                                                                                       \
   [ent] "s"(ent), [desc] "s"(desc), [X] "s"(X), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8), [l4] "v"(l4), \
       [l128] "v"(l128), [col16] "v"(col16), [rowb0] "v"(rowb0), [nct] "s"(nct), [stride] "s"(stride), [prm1] "s"(prm1),      \
-      [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [cw] "s"(cw)
+      [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [cw] "s"(cw), [mode] "s"(mode)
     if constexpr (RG == 8) {
       asm volatile(DQ_MAIN_ASM_8
                    : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)
@@ -197,10 +197,11 @@ bool dq_usable(const TiledOp& op, int ldx) {
 template <int RG>
 static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s) {
   static LdsAttrState attr;
+  static const int mode = getenv("SAPCA_DQ_MODE") ? atoi(getenv("SAPCA_DQ_MODE")) : 0;   // 1: tile loop without compute (timing only)
   ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_dq_kernel<RG>), DQ_LDS, attr);
   hipLaunchKernelGGL(spmm_dq_kernel<RG>, dim3((unsigned)(op.nrb * op.nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm,
                      op.nct, reinterpret_cast<const uint64_t*>(op.ent), op.dq_desc, op.dq_info, op.cols, X, ldx, op.nsplit,
-                     op.tiles_per_split, out, op.rows, ldo, ncols, cvec);
+                     op.tiles_per_split, out, op.rows, ldo, ncols, cvec, mode);
 }
 
 void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s) {

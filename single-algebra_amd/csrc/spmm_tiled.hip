@@ -1355,10 +1355,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   const int waves = quad ? QWAVES : waves_for(slots);
   // (the DPP-fed sweep double-buffers the default 80 KiB tile and holds 8 or 16 row slots per lane group: f32 operators
   // with 64-column tiles keep that split, and take 1024-row blocks -- half the tile refills and barriers per entry --
-  // when that still leaves a row block for most CUs)
+  // when the operator has at least 16 of them (A^T of a tall matrix: the tile range is split over workgroups instead))
   const bool dq_candidate = f32 && quad && ldp == 64 && getenv("SAPCA_NO_DQ") == nullptr;
   static const int dq_rows_env = getenv("SAPCA_DQ_BLOCK_ROWS") ? atoi(getenv("SAPCA_DQ_BLOCK_ROWS")) : 0;
-  const int block_rows = dq_candidate ? (dq_rows_env == 512 || dq_rows_env == 1024 ? dq_rows_env : (op_rows >= 1024 * 192 ? 1024 : 512))
+  const int block_rows = dq_candidate ? (dq_rows_env == 512 || dq_rows_env == 1024 ? dq_rows_env : (op_rows >= 1024 * 16 ? 1024 : 512))
                          : quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
                                 : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
   int stage_cap = quad ? q_stage_bytes(tile_bytes) / (int)sizeof(E) - WAVE : STAGE_ENTRIES;
@@ -1369,8 +1369,11 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   } else {
     // few row blocks (A^T): split the tile range so that (blocks x splits) lands just under a
     // multiple of the 256 CUs -- one workgroup per CU per round, no half-empty last round
-    nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, 512 / nrb));
-    const int64_t nrb_fit = 512 / nsplit;
+    static const int split_wgs_env = getenv("SAPCA_SPLIT_WGS") ? atoi(getenv("SAPCA_SPLIT_WGS")) : 0;
+    // 1024-row blocks fill a CU's LDS and registers alone: one workgroup per CU; the others run two per CU
+    const int64_t split_wgs = split_wgs_env > 0 ? split_wgs_env : (block_rows > 512 ? 256 : 512);
+    nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, split_wgs / nrb));
+    const int64_t nrb_fit = split_wgs / nsplit;
     if (nrb_fit >= nrb && nrb_fit <= op_rows) nrb = nrb_fit;
   }
   // the bigger tile (fewer, longer tile steps, less quad padding) when the chunks are expected to leave room

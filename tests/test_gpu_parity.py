@@ -695,6 +695,23 @@ def test_transform_of_a_matrix_that_was_not_fitted(dtype):
                       sp.csr_matrix((10, n + 1), dtype=dtype))
 
 
+def test_transform_after_the_values_were_edited_in_place():
+    """fit(X) on caller-owned device arrays, X.values edited in place through torch, transform(X): the projection must
+    see the new values (the preparation kept from the fit -- a tile-major copy of the values -- is not reused across
+    separate calls on caller-owned pointers), with the column counts (Q2) of the unchanged pattern."""
+    m, n, k = 3000, 600, 6
+    dev = synth.gapped_csr(m, n, 0.05, k, seed=12, dtype=torch.float32, device="cuda")
+    x = sapca.DeviceCsr(*dev, (m, n))
+    pca = _builder(k, 6, 2).spmm_variant(2).build()
+    t_fit = pca.fit_transform(x).cpu().numpy()
+    dev[2].mul_(3.0).add_(0.25)
+    t = pca.transform(x).cpu().numpy()
+    ptr, idx, val = csr_np(dev)
+    want = O.transform_sparse(ptr, idx, val.astype(np.float64), m, n, pca.components_(np.float64), pca.mean_(np.float64), True)
+    np.testing.assert_allclose(t, want, atol=2e-3 * np.abs(want).max())
+    assert np.abs(t - t_fit).max() > 0.1 * np.abs(t_fit).max()   # and it is not the projection of the fitted values
+
+
 def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     """A^T's tile-major format can come from the tile-major transposed rows still packed by the sort (default),
     from the same rows unpacked into a CSR, from a naturally ordered transposed CSR, or straight from A: the

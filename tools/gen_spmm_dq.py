@@ -34,6 +34,7 @@ S_T, S_NT, S_CW, S_TABS, S_BUF, S_NCH, S_OFF8 = 44, 45, 46, 47, 48, 49, 50
 S_A, S_B2, S_C, S_D, S_E = 51, 52, 53, 54, 55
 S_INFO = 56       # s[56:57] info pointer of the current 64-tile window
 S_4NCT, S_TLAST, S_DL1 = 58, 59, 60
+S_CI, S_DROW, S_DLDS = 61, 62, 63
 
 
 def grp_a(k, e, L):
@@ -62,12 +63,54 @@ def grp_b(k, L, wait):
         L.append(f"s_lshr_b32 s{sd}, s{sd}, 8")
 
 
+def dma_piece(L):
+    """one 1 KiB LDS-DMA piece of the next tile: 4 panel rows x 256 bytes (lane: row S_DROW-relative, 16 bytes of it)"""
+    L.append(f"v_add_u32 v{VT}, s{S_DROW}, %[rowb0]")
+    L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
+    L.append(f"v_mul_lo_u32 v{VT}, v{VT}, %[stride]")
+    L.append(f"v_add_u32 v{VT}, %[col16], v{VT}")
+    L.append(f"s_mov_b32 m0, s{S_DLDS}")
+    L.append("s_nop 0")
+    L.append(f"global_load_lds_dwordx4 v{VT}, %[X]")
+    L.append(f"s_add_u32 s{S_DROW}, s{S_DROW}, s{S_4NCT}")
+    L.append(f"s_add_u32 s{S_DLDS}, s{S_DLDS}, 0x400")
+
+
+def prefetch_next_stream(L):
+    """L2 prefetch of the next tile's entry stream (lane * 128 bytes, clamped to the stream)"""
+    L += [f"s_add_u32 s{S_A}, s{S_T}, 1", f"s_and_b32 s{S_A}, s{S_A}, 63", f"s_add_u32 s{S_C}, s{S_T}, 1",
+          f"s_cmp_lt_u32 s{S_C}, s{S_NT}", "s_cselect_b32 s%d, s%d, 0" % (S_C, S_A),            # window lane of the next tile, or 0
+          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b32 s{S_C}, s{S_T}, s{S_C}",                    # ... lane 0 = a new window (or no next tile): prefetch the current one
+          f"s_and_b32 s{S_C}, s{S_C}, 63",
+          f"v_readlane_b32 s{S_A}, v{VINFO[0]}, s{S_C}", f"v_readlane_b32 s{S_E}, v{VINFO[1]}, s{S_C}"]
+    ptr_from_off8(L, S_A, S_DP, "ent")
+    L += [f"s_lshl_b32 s{S_E}, s{S_E}, 9", f"s_max_u32 s{S_E}, s{S_E}, 4", f"s_sub_u32 s{S_E}, s{S_E}, 4",
+          f"v_min_u32 v{VT}, s{S_E}, %[l128]", f"global_load_dword v{VPF}, v{VT}, s[{S_DP}:{S_DP + 1}]"]
+
+
 def chunk_body(buf, L, lbl):
-    """16 steps from entry buffer `buf`.  On entry the buffer's load has been waited for.  Before the last group's
-    DPP reads are issued nothing may overwrite the buffer; its reload (the chunk three ahead, if the stream has one)
-    is issued right after them."""
+    """Chunk S_CI of the tile (16 steps) from entry buffer `buf` = S_CI mod 3.
+
+    Vector-memory operations return in order, so the wait for this chunk's entries also waits for everything issued
+    before them and is written as a count of what was issued after them.  Per tile, in issue order:
+      E0 E1 E2 descriptor | barrier | chunk 0: prefetch, piece 0, reload 3 | chunk 1: piece 1, reload 4 | ... | leftover pieces
+    (piece c = one of this wave's five LDS-DMA pieces of the NEXT tile, issued in chunk c so that no entry load ever
+    queues behind a burst of them; reload c + 3 only where the stream has such a chunk).  Chunk 0 waits for everything,
+    chunks 1 and 2 for nothing (their entries are older than the descriptor), chunk c >= 3 for
+      [c - 2 < 5] + [c - 1 < 5] + [c + 1 < nch] + [c + 2 < nch]   younger operations."""
     e = EB[buf]
     depth = 2
+    L += [f"s_cmp_lt_u32 s{S_CI}, 7", f"s_cbranch_scc1 {lbl}_ws", f"s_cmp_lt_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_ws",
+          "s_waitcnt vmcnt(2)", f"s_branch {lbl}_wz", f"{lbl}_ws:",     # steady state: two reloads behind this chunk's entries
+          f"s_cmp_eq_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_wf", f"s_cmp_lt_u32 s{S_CI}, 3", f"s_cbranch_scc1 {lbl}_wz",
+          f"s_sub_i32 s{S_A}, 7, s{S_CI}", f"s_max_i32 s{S_A}, s{S_A}, 0", f"s_min_i32 s{S_A}, s{S_A}, 2",
+          f"s_sub_u32 s{S_B2}, s{S_REM}, 1", f"s_min_u32 s{S_B2}, s{S_B2}, 2", f"s_add_u32 s{S_A}, s{S_A}, s{S_B2}"]
+    for n in (4, 3, 2, 1):
+        L += [f"s_cmp_lg_u32 s{S_A}, {n}", f"s_cbranch_scc1 {lbl}_w{n - 1}", f"s_waitcnt vmcnt({n})", f"s_branch {lbl}_wz", f"{lbl}_w{n - 1}:"]
+    L += ["s_waitcnt vmcnt(0)", f"s_branch {lbl}_wz", f"{lbl}_wf:", "s_waitcnt vmcnt(0)"]
+    if buf == 0:
+        prefetch_next_stream(L)
+    L += [f"{lbl}_wz:"]
     L.append(f"s_add_u32 s{S_DL1}, s{S_DL}, 1")
     L.append(f"v_readlane_b32 s{S_D0}, v{VDESC}, s{S_DL}")
     L.append(f"v_readlane_b32 s{S_D1}, v{VDESC}, s{S_DL1}")
@@ -79,32 +122,19 @@ def chunk_body(buf, L, lbl):
         if k + depth < 8:
             grp_a(k + depth, e, L)
             if k + depth == 7:
+                L += [f"s_cmp_ge_u32 s{S_CI}, 5", f"s_cbranch_scc1 {lbl}_nodma"]
+                dma_piece(L)
+                L += [f"{lbl}_nodma:"]
                 # reload: chunk c + 3 exists  <=>  rem > 3   (rem counts the current chunk)
                 L.append(f"s_cmp_le_u32 s{S_REM}, 3")
                 L.append(f"s_cbranch_scc1 {lbl}_norel")
-                L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536")
+                L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536 nt")
                 L.append(f"{lbl}_norel:")
     L.append(f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200")
     L.append(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
     L.append(f"s_add_u32 s{S_DL}, s{S_DL}, 2")
     L.append(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
-
-
-def dma(L, s_tile, s_bufbase):
-    """this wave's five 1 KiB pieces of tile `s_tile` (absolute index, SGPR number) into the LDS buffer at SGPR s_bufbase"""
-    L.append(f"s_mov_b32 s{S_A}, s{s_tile}")
-    L.append(f"s_add_u32 s{S_B2}, s{s_bufbase}, %[wdma]")
-    for i in range(5):
-        L.append(f"v_add_u32 v{VT}, s{S_A}, %[rowb0]")
-        L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
-        L.append(f"v_mul_lo_u32 v{VT}, v{VT}, %[stride]")
-        L.append(f"v_add_u32 v{VT}, %[col16], v{VT}")
-        L.append(f"s_mov_b32 m0, s{S_B2}")
-        L.append("s_nop 0")
-        L.append(f"global_load_lds_dwordx4 v{VT}, %[X]")
-        if i < 4:
-            L.append(f"s_add_u32 s{S_A}, s{S_A}, s{S_4NCT}")
-            L.append(f"s_add_u32 s{S_B2}, s{S_B2}, 0x400")
+    L.append(f"s_add_u32 s{S_CI}, s{S_CI}, 1")
 
 
 def ptr_from_off8(L, s_off8, dst, base):
@@ -128,55 +158,40 @@ def body():
           f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1"]
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
-    # first tile: synchronous LDS-DMA into buffer 0
-    dma(L, S_TABS, S_BUF)
-    L += ["s_waitcnt vmcnt(0)"]
+    # first tile: this wave's five pieces into buffer 0, synchronously
+    L += [f"s_mov_b32 s{S_DROW}, s{S_TABS}", f"s_mov_b32 s{S_DLDS}, %[wdma]", f"s_mov_b32 s{S_CI}, 0", "13:"]
+    dma_piece(L)
+    L += [f"s_add_u32 s{S_CI}, s{S_CI}, 1", f"s_cmp_lt_u32 s{S_CI}, 5", "s_cbranch_scc1 13b", "s_waitcnt vmcnt(0)"]
     L += ["10:"]   # ---- tile loop
     # a new 64-tile window of the info table
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"s_cmp_lg_u32 s{S_A}, 0", "s_cbranch_scc1 11f", f"s_cmp_eq_u32 s{S_T}, 0",
           "s_cbranch_scc1 11f", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
           f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]", "s_waitcnt vmcnt(0)", "11:"]
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}",
-          f"s_min_u32 s{S_NCH}, s{S_NCH}, 32"]   # the builder guarantees it; a corrupt table must not turn into an endless loop
+          f"s_min_u32 s{S_NCH}, s{S_NCH}, 32",   # the builder guarantees it; a corrupt table must not turn into an endless loop
+          "s_bitcmp1_b32 %[mode], 0", f"s_cselect_b32 s{S_NCH}, 0, s{S_NCH}"]   # diagnostics (SAPCA_DQ_MODE=1): tiles without compute
     ptr_from_off8(L, S_OFF8, S_PTR, "ent")
     # descriptor chunk index = off8 / 8 + cw  (8 bytes each)
     L += [f"s_lshr_b32 s{S_E}, s{S_OFF8}, 3", f"s_add_u32 s{S_E}, s{S_E}, s{S_CW}", f"s_lshl_b32 s{S_C}, s{S_E}, 3", f"s_lshr_b32 s{S_D}, s{S_E}, 29",
           f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[desc]", f"s_add_u32 s{S_DP}, s{S_DP}, s{S_C}", f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, s{S_D}"]
     for i, e in enumerate(EB):
-        L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i}")
+        L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i} nt")
     L.append(f"global_load_dword v{VDESC}, %[l4], s[{S_DP}:{S_DP + 1}]")
-    # this wave's pieces of the tile have landed (younger: prefetch, reloads -- long complete -- and the four loads above)
+    # this wave's pieces of the tile have landed: everything but the four loads above is waited for
     L += ["s_waitcnt vmcnt(4)", "s_barrier"]
-    # next tile -> the other buffer (the last tile reloads itself: keeps the wait counts below static)
-    L += [f"s_add_u32 s{S_E}, s{S_TABS}, 1", f"s_min_u32 s{S_E}, s{S_E}, s{S_TLAST}", f"s_sub_u32 s{S_C}, {TILE_B}, s{S_BUF}"]
-    L += [f"s_mov_b32 s{S_D}, s{S_C}"]
-    dma_next = []
-    dma(dma_next, S_E, S_D)
-    L += dma_next
-    # L2 prefetch of the next tile's entry stream (lane * 128 bytes, clamped to the stream)
-    L += [f"s_add_u32 s{S_A}, s{S_T}, 1", f"s_and_b32 s{S_A}, s{S_A}, 63", f"s_add_u32 s{S_C}, s{S_T}, 1",
-          f"s_cmp_lt_u32 s{S_C}, s{S_NT}", "s_cselect_b32 s%d, s%d, 0" % (S_C, S_A),            # window lane of the next tile, or 0
-          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b32 s{S_C}, s{S_T}, s{S_C}",                    # ... lane 0 = a new window (or no next tile): prefetch the current one
-          f"s_and_b32 s{S_C}, s{S_C}, 63",
-          f"v_readlane_b32 s{S_A}, v{VINFO[0]}, s{S_C}", f"v_readlane_b32 s{S_E}, v{VINFO[1]}, s{S_C}"]
-    ptr_from_off8(L, S_A, S_DP, "ent")
-    L += [f"s_lshl_b32 s{S_E}, s{S_E}, 9", f"s_max_u32 s{S_E}, s{S_E}, 4", f"s_sub_u32 s{S_E}, s{S_E}, 4",
-          f"v_min_u32 v{VT}, s{S_E}, %[l128]", f"global_load_dword v{VPF}, v{VT}, s[{S_DP}:{S_DP + 1}]"]
-    L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}", f"s_mov_b32 s{S_DL}, 0"]
-    # peeled chunks 0..2: younger than E0..E2 and the descriptor are the 5 LDS-DMA pieces and the prefetch
-    for i in range(3):
-        L += [f"s_cmp_eq_u32 s{S_REM}, 0", "s_cbranch_scc1 19f"]
-        if i == 0:   # the wait also covers E1, E2 (older than the descriptor): chunks 1 and 2 need none
-            L += ["s_waitcnt vmcnt(6)"]
-        chunk_body(i, L, f"pc{i}")
-    # steady state: chunk c >= 3 from buffer c % 3; its load is followed by those of c + 1, c + 2 where they exist
+    # pieces of the next tile go to the other buffer (the last tile reloads itself: harmless, keeps the counts uniform)
+    L += [f"s_add_u32 s{S_DROW}, s{S_TABS}, 1", f"s_min_u32 s{S_DROW}, s{S_DROW}, s{S_TLAST}", f"s_sub_u32 s{S_DLDS}, {TILE_B}, s{S_BUF}",
+          f"s_add_u32 s{S_DLDS}, s{S_DLDS}, %[wdma]"]
+    L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}", f"s_mov_b32 s{S_DL}, 0", f"s_mov_b32 s{S_CI}, 0"]
     L += ["12:"]
     for i in range(3):
         L += [f"s_cmp_eq_u32 s{S_REM}, 0", "s_cbranch_scc1 19f"]
-        L += [f"s_cmp_ge_u32 s{S_REM}, 3", f"s_cbranch_scc1 q{i}_2", f"s_cmp_eq_u32 s{S_REM}, 2", f"s_cbranch_scc1 q{i}_1",
-              "s_waitcnt vmcnt(0)", f"s_branch q{i}_z", f"q{i}_1:", "s_waitcnt vmcnt(1)", f"s_branch q{i}_z", f"q{i}_2:", "s_waitcnt vmcnt(2)", f"q{i}_z:"]
-        chunk_body(i, L, f"sc{i}")
+        chunk_body(i, L, f"c{i}")
     L += ["s_branch 12b", "19:"]
+    # pieces the chunks did not issue (fewer than five chunks)
+    L += [f"s_cmp_ge_u32 s{S_CI}, 5", "s_cbranch_scc1 18f", "17:"]
+    dma_piece(L)
+    L += [f"s_add_u32 s{S_CI}, s{S_CI}, 1", f"s_cmp_lt_u32 s{S_CI}, 5", "s_cbranch_scc1 17b", "18:"]
     L += [f"s_add_u32 s{S_T}, s{S_T}, 1", f"s_add_u32 s{S_TABS}, s{S_TABS}, 1", f"s_add_u32 s{S_CW}, s{S_CW}, 16",
           f"s_sub_u32 s{S_BUF}, {TILE_B}, s{S_BUF}", f"s_cmp_lt_u32 s{S_T}, s{S_NT}", "s_cbranch_scc1 10b"]
     L += ["s_waitcnt vmcnt(0)"]
@@ -201,7 +216,7 @@ def uniq_labels(L):
 
 def clobbers():
     v = [f"v{i}" for i in range(10, 48)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 4)]
-    s = [f"s{i}" for i in range(36, 61)]
+    s = [f"s{i}" for i in range(36, 64)]
     return v + s + ["memory", "scc", "m0"]
 
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/pmc_dq.sh <tag> "<counters>" -- one rocprofv3 --pmc pass over bench.py --steps 1; per-kernel averages of the sweep kernels
+cd /tmp; export TMPDIR=/tmp
+tag=$1; shift
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.err
+python3 - <<PY
+import csv,glob,collections
+f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/*/*counter_collection.csv")
+if not f: print("no counter file"); raise SystemExit
+acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+for r in csv.DictReader(open(f[0])):
+    k=r["Kernel_Name"]
+    if "spmm_dq" not in k and "spmm_quad" not in k: continue
+    k=k.split("(")[0][-40:]+" grid "+r.get("Grid_Size","?")
+    acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
+for k in acc:
+    print(k)
+    for c,v in acc[k].items(): print("   %-28s %.4g  x%d" % (c, v/cnt[(k,c)], cnt[(k,c)]))
+PY
