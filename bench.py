@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- SparsePCA fit_transform on synthetic CSR, MI355X, one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --scaling strong [--workload c4|c5]   (one matrix split over the ranks: BASELINE configs[3], [4])
 
 A "step" is one fit_transform of the hot path over a device-resident CSR (inputs already in
 HBM when the timed region starts).  At N=1 the workload is BASELINE.json configs[1] (C2:
@@ -113,34 +114,145 @@ def bench_lanczos(args, rank, local_rank, world, dev):
     assert out.shape == (m, k)
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` started by hand: one child per GPU through torch.distributed.run, started BEFORE this
+    process touches a GPU; the parent relays rank 0's JSON line and the children's exit status."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    raise SystemExit(proc.returncode)
+
+
+def measured_copy_gbs(dev, nbytes=1 << 30, reps=5):
+    """Attainable HBM rate of this device: a device-to-device copy of `nbytes` (read + write counted), best of `reps`."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    best = float("inf")
+    for _ in range(reps + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.copy_(src)
+        b.record()
+        b.synchronize()
+        best = min(best, a.elapsed_time(b))
+    del src, dst
+    return 2.0 * nbytes / (best * 1e-3) / 1e9
+
+
+def c1_comparison(dev, local_rank):
+    """BASELINE.json configs[0] (the reference's CPU-runnable case: 10k x 2k f64, 5 %, k=20, p=10, q=4): the restatement
+    on the full problem next to the GPU's fit_transform of the same matrix."""
+    import sapca
+    from sapca import synth
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    m, n, density, k, p, q = 10_000, 2_000, 0.05, 20, 10, 4
+    ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=42, dtype=torch.float64, device=dev)
+    x = sapca.DeviceCsr(ptr, idx, val, (m, n))
+    pca = (sapca.SparsePCABuilder.new().n_components(k).random_seed(42).device(local_rank)
+           .svd_method(sapca.SVDMethod.Random(p, q, sapca.PowerIterationNormalizer.QR)).build())
+    for _ in range(3):
+        pca.fit_transform(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        pca.fit_transform(x)
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / 10 * 1e3
+    hp, hi, hv = ptr.cpu().numpy(), idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
+    om = synth.gaussian_panel(n, k + p, 42).numpy()
+    t0 = time.perf_counter()
+    rc, comps, sing, ev, mean, tv = orc.randomized_fit(hp, hi, hv, m, n, k, p, q, "QR", True, om)
+    orc.transform_sparse(hp, hi, hv, m, n, comps, mean, True)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    _, total = alg_bytes(m, n, len(hv), k + p, k, q, tsize=8)
+    return {"workload": f"c1: {m} x {n} CSR f64 density {density}, k={k} p={p} q={q} QR (BASELINE.json configs[0])",
+            "value": total / (cpu_ms * 1e-3) / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "kind": "port", "cpu_ms": cpu_ms,
+            "gpu_ms": gpu_ms, "sample": "the full problem, fit + closed-form transform; restatement of the reference algorithm"}
+
+
+def e2e_host_ms(args, m, n, density, k, p, q, dev, local_rank):
+    """One fit_transform through the HOST entry point the reference signature maps to (usize indices in host memory ->
+    result in host memory: index narrowing, PCIe, fit, projection, download); outside the timed loop."""
+    import sapca
+    import scipy.sparse as sp
+    from sapca import synth
+    ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=42, dtype=torch.float32, device=dev)
+    a = sp.csr_matrix((val.cpu().numpy(), idx.cpu().numpy().astype(np.int64), ptr.cpu().numpy()), shape=(m, n))
+    del ptr, idx, val
+    pca = (sapca.SparsePCABuilder.new().n_components(k).random_seed(42).device(local_rank)
+           .svd_method(sapca.SVDMethod.Random(p, q, sapca.PowerIterationNormalizer.QR)).build())
+    pca.fit_transform(a)                     # first call allocates the device buffers and pins the staging ring
+    t0 = time.perf_counter()
+    pca.fit_transform(a)
+    return (time.perf_counter() - t0) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank holds the workload's rows (default, c2 shards); strong: the workload's rows are split "
+                         "over the ranks (default workload c4: 1M x 30k, BASELINE.json configs[3])")
     ap.add_argument("--spmm-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measured copy rate, the host-path run and the C1 comparison")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c4" if args.scaling == "strong" else "c2"
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    shared = world > ndev                     # fewer GPUs than ranks (a one-GPU box rehearsing the launcher): ranks share
+    local_rank = local_rank % max(ndev, 1)    # devices and the collectives go through gloo on host copies
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    rdev = torch.device("cpu") if shared else dev     # where this script's own small reductions live
 
     import sapca
     from sapca import synth
-    m, n, density, k, p, q = WORKLOADS[args.workload]
+    m_cfg, n, density, k, p, q = WORKLOADS[args.workload]
     seed = 42
     if args.workload == "c3":
         return bench_lanczos(args, rank, local_rank, world, dev)
-    ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=seed, row_start=rank * m, dtype=torch.float32, device=dev)
+    if args.scaling == "strong":
+        # rows of the one m_cfg-row matrix, split evenly: the generator's rows are identically distributed, so equal row
+        # counts are entry-balanced to 0.1 % (sapca_partition_rows does the same from the row offsets of a host matrix)
+        r0, r1 = m_cfg * rank // world, m_cfg * (rank + 1) // world
+        m_total = m_cfg
+    else:
+        r0, r1 = rank * m_cfg, (rank + 1) * m_cfg
+        m_total = m_cfg * world
+    m = r1 - r0
+    ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=seed, row_start=r0, dtype=torch.float32, device=dev)
     x = sapca.DeviceCsr(ptr, idx, val, (m, n))
     nnz = x.nnz
     pca = (sapca.SparsePCABuilder.new().n_components(k).random_seed(42).device(local_rank).collect_timings(True)
@@ -149,7 +261,10 @@ def main():
     transport = "none"
     if world > 1:
         from sapca import dist as sdist
-        transport = sdist.init_comm(pca)        # RCCL inside the library; torch.distributed callback as the fallback
+        # RCCL inside the library; torch.distributed callback as the fallback (and the only way when ranks share a GPU)
+        transport = sdist.init_comm(pca, prefer="torch" if shared else "rccl", stage_through_host=shared)
+        if shared:
+            transport += " (gloo on host copies: ranks share a GPU)"
 
     def barrier():
         if world > 1:
@@ -170,22 +285,27 @@ def main():
             stage[f] = stage.get(f, 0.0) + getattr(t, f) / args.steps
     barrier()
     dt = time.perf_counter() - t0
+    avg_sweep_ms = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
+    per_rank_sweep = [avg_sweep_ms]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        nn = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
+        nn = torch.tensor([float(nnz)], dtype=torch.float64, device=rdev)
         dist.all_reduce(nn)
         nnz_total = float(nn.item())
+        sw = torch.zeros(world, dtype=torch.float64, device=rdev)
+        sw[rank] = avg_sweep_ms
+        dist.all_reduce(sw)
+        per_rank_sweep = [float(v) for v in sw.tolist()]
     else:
         nnz_total = float(nnz)
     assert out.shape == (m, k) and bool(torch.isfinite(out).all())
 
     l = k + p
     sweep_bytes, _ = alg_bytes(m, n, nnz, l, k, q)                      # per rank (one launch)
-    _, total_bytes = alg_bytes(m * world, n, nnz_total, l, k, q)        # whole job
+    _, total_bytes = alg_bytes(m_total, n, nnz_total, l, k, q)          # whole job
     ms_per_step = dt / args.steps * 1e3
-    avg_sweep_ms = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
     achieved = sweep_bytes / (avg_sweep_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -195,22 +315,47 @@ def main():
         except Exception:
             traffic = None
     if rank == 0:
+        t = pca.timings()
+        kernel_names = {0: "spmm_rowgather_kernel", 1: "spmm_quad_kernel (entries staged in LDS)", 2: "spmm_dq_kernel (DPP-fed quad sweep)"}
+        slots = 0.5 * (t.sweep_slots_a + t.sweep_slots_at)
+        lds_bytes = slots * 4 * 64                                      # one 256-byte panel row gathered from LDS per entry slot
         line = {
             "metric": "sparse_pca_fit_transform_algorithmic_throughput", "value": total_bytes / (dt / args.steps) / 1e9,
             "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {m * world} x {n} CSR f32, density {density}, gapped generator seed {seed}, "
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {m_total} x {n} CSR f32, density {density}, gapped generator seed {seed}, "
                                    f"SparsePCA fit_transform, SVDMethod::Random k={k} p={p} q={q} QR, rows range-partitioned "
-                                   f"over {world} GPU(s), inputs resident in HBM, collectives: {transport}",
-                       "nnz": int(nnz_total), "rows_per_gpu": m, "sweeps_per_fit": 2 * q + 2, "stage_ms": stage},
+                                   f"over {world} GPU(s) ({args.scaling} scaling), inputs resident in HBM, collectives: {transport}",
+                       "nnz": int(nnz_total), "rows_per_gpu": m, "sweeps_per_fit": 2 * q + 2, "stage_ms": stage,
+                       "collectives": transport, "comm_ms": stage.get("comm_ms", 0.0), "sweep_ms_per_rank": per_rank_sweep},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "spmm sweep (A*X and A^T*Y launches, HIP events on the library stream)",
+                         "kernel": f"{kernel_names.get(int(t.sweep_kernel), '?')}: spmm sweep (A*X and A^T*Y launches, HIP events on the library stream)",
                          "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_ms,
                          "launches_timed": len(sweep_ms)},
         }
+        if slots > 0:
+            # what binds the sweep in practice: every entry slot gathers a 256-byte panel row from LDS and costs four
+            # wave-level VALU instructions per four slots; the guide's aggregate ds_read_b128 rate is ~150 TB/s
+            line["roofline"]["secondary"] = {"bound": "lds", "achieved": lds_bytes / (avg_sweep_ms * 1e-3) / 1e9, "peak": 150000.0,
+                                             "unit": "GB/s", "frac": lds_bytes / (avg_sweep_ms * 1e-3) / 1e9 / 150000.0,
+                                             "lds_gather_bytes_per_launch": lds_bytes, "entry_slots_per_launch": slots,
+                                             "stored_entries_per_launch": int(nnz)}
+        if not args.no_extras:
+            del out
+            peak_meas = measured_copy_gbs(dev)
+            line["roofline"]["peak_measured"] = peak_meas
+            line["roofline"]["frac_of_measured"] = achieved / peak_meas
+        if world == 1 and not args.no_extras:
+            try:
+                line["e2e_host_ms"] = e2e_host_ms(args, m, n, density, k, p, q, dev, local_rank)
+            except Exception as e:   # never lose the line to an extra
+                line["e2e_host_ms"] = None
+                line["e2e_host_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, n, density, k, p, q, seed, dev)
+            if not args.no_extras:
+                line["cpu_baseline_c1"] = c1_comparison(dev, local_rank)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

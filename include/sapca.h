@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SAPCA_ABI_VERSION 1
+#define SAPCA_ABI_VERSION 2   /* 2: sapca_timings grew sweep_kernel / sweep_slots_*; sapca_comm_rccl_available */
 
 typedef struct sapca_handle_s* sapca_handle;
 
@@ -99,7 +99,8 @@ typedef struct sapca_timings {
   double small_svd_ms;       /* final factorisation incl. host Jacobi                           */
   double lanczos_ms;
   double transform_ms;
-  double comm_ms;            /* host-observed time in collectives                               */
+  double comm_ms;            /* collectives: device time (events around every all-reduce) when
+                              * timings are collected, host-observed time otherwise            */
   double fit_total_ms;
   uint32_t n_spmm;           /* number of A*X sweeps timed                                      */
   uint32_t n_spmmt;
@@ -107,6 +108,12 @@ typedef struct sapca_timings {
   double spmmt_sweep_ms[32];
   double bytes_per_sweep;    /* ALGORITHMIC bytes of one sweep (SURVEY.md §8d formula)          */
   uint64_t lanczos_steps;
+  uint32_t sweep_kernel;     /* randomized fits: 0 row-gather kernel, 1 staged-entry quad sweep,
+                              * 2 DPP-fed quad sweep (spmm_dq.hip)                              */
+  uint32_t reserved0;
+  uint64_t sweep_slots_a;    /* entry slots (stored entries + padding) one A*X sweep walks; 0 on
+                              * the row-gather kernel.  x 256 B (f32, 64 columns) = LDS gather bytes */
+  uint64_t sweep_slots_at;   /* the same for one A^T*Y sweep                                    */
 } sapca_timings;
 
 void sapca_options_default(sapca_options* o);
@@ -276,6 +283,9 @@ sapca_status sapca_stats_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, 
 sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint32_t nparts, uint64_t* bounds);
 /* Built-in collective = RCCL (resolved at run time from librccl.so.1).  Rank 0 creates the
  * 128-byte id and the host program distributes it (torch.distributed broadcast, MPI, a file).  */
+/* 1 when librccl and its entry points resolve in this process: every rank checks this BEFORE the
+ * collective ncclCommInitRank inside sapca_comm_init_rank, which must not fail on some ranks only. */
+int sapca_comm_rccl_available(void);
 sapca_status sapca_comm_unique_id(uint8_t id[128]);
 sapca_status sapca_comm_init_rank(sapca_handle h, uint32_t nranks, uint32_t rank, const uint8_t id[128]);
 /* Or bring your own all-reduce(sum) over all ranks: `buf` is a DEVICE pointer holding `count`

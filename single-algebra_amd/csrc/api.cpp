@@ -698,6 +698,8 @@ sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint3
   return SAPCA_OK;
 }
 
+int sapca_comm_rccl_available(void) { return sapca::Comm::rccl_available() ? 1 : 0; }
+
 sapca_status sapca_comm_unique_id(uint8_t id[128]) {
   if (!id) return SAPCA_ERR_ARG;
   try {

@@ -54,6 +54,15 @@ void check(int rc, const char* what) {
 
 }  // namespace
 
+bool Comm::rccl_available() {
+  try {
+    (void)api();
+    return true;
+  } catch (const Error&) {
+    return false;
+  }
+}
+
 void Comm::unique_id(uint8_t id[128]) {
   RcclId u;
   check(api().GetUniqueId(&u), "ncclGetUniqueId");

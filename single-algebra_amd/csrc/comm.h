@@ -22,6 +22,7 @@ struct Comm {
   void allreduce(void* buf, uint64_t count, int dtype, hipStream_t s);
   void destroy();
   static void unique_id(uint8_t id[128]);
+  static bool rccl_available();   // librccl and the four entry points resolve in this process
 };
 
 }  // namespace sapca

@@ -15,6 +15,7 @@
 
 #include "lanczos.h"
 #include "small_svd.h"
+#include "spmm_dq.h"
 
 namespace sapca {
 
@@ -22,7 +23,7 @@ namespace {
 
 constexpr size_t kSmallDoubles = (size_t)6 * 128 * 128 + 64 + 4 * 128;
 
-enum Cat { C_PREPARE, C_STATS, C_SPMM, C_SPMMT, C_ORTHO, C_SMALL, C_LANCZOS, C_TRANSFORM, C_COUNT };
+enum Cat { C_PREPARE, C_STATS, C_SPMM, C_SPMMT, C_ORTHO, C_SMALL, C_LANCZOS, C_TRANSFORM, C_COMM, C_COUNT };
 
 struct Scope {
   sapca_handle_s& h;
@@ -47,6 +48,7 @@ void collect_timings(sapca_handle_s& h, bool is_fit) {
   } else {
     t.transform_ms = 0;
   }
+  double comm_dev_ms = 0;
   for (auto& sp : h.spans) {
     if (is_fit == (sp.first == C_TRANSFORM)) continue;  // fit spans on fit, transform spans on transform
     const double ms = h.timer.ms(sp.second);
@@ -67,10 +69,13 @@ void collect_timings(sapca_handle_s& h, bool is_fit) {
       case C_SMALL: t.small_svd_ms += ms; break;
       case C_LANCZOS: t.lanczos_ms += ms; break;
       case C_TRANSFORM: t.transform_ms += ms; break;
+      case C_COMM: comm_dev_ms += ms; break;
       default: break;
     }
   }
-  t.comm_ms = h.comm.host_ms;
+  // collectives: device time between events around every all-reduce on the library stream (what the GPU waited);
+  // the host-observed time is what remains when timings are not collected
+  if (is_fit) t.comm_ms = comm_dev_ms > 0 ? comm_dev_ms : h.comm.host_ms;
 }
 
 }  // namespace
@@ -167,7 +172,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
     const double m_local = (double)m;
     SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &m_local, sizeof(double), hipMemcpyHostToDevice, s));
-    if (h.comm.active()) h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s);
+    if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s); }
     SAPCA_HIP(hipMemcpyAsync(sums.data(), d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipMemcpyAsync(&sums[(size_t)2 * n], d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));
@@ -292,7 +297,7 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
   const int passes = passes_hint > 0 ? passes_hint : (normalizer == SAPCA_NORM_QR ? 2 : 1);
   for (int pass = 0; pass < passes; ++pass) {
     k::gram(P, rows, ld, G, h.scratch2, s);
-    if (sharded && h.comm.active()) h.comm.allreduce(G, (uint64_t)ld * ld, 1, s);
+    if (sharded && h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(G, (uint64_t)ld * ld, 1, s); }
     double* Rout = pass == 0 ? (R1 ? R1 : Rtmp) : (R2 ? R2 : Rtmp);
     k::chol_inv(G, l, ld, Rout, Rinv, info, s);
     k::panel_gemm(P, rows, ld, Rinv, ld, P, s);
@@ -362,7 +367,7 @@ void Engine<T>::fit_randomized(H& h) {
     // one collective per sweep: the l column sums of this rank's Y sit in the row after the panel
     T* sv = h.comm.active() ? X + (size_t)n_used * ld : svec;
     if (center) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
-    if (h.comm.active()) h.comm.allreduce(X, (uint64_t)n_used * ld + (center ? (uint64_t)ld : 0), kDtype, s);
+    if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(X, (uint64_t)n_used * ld + (center ? (uint64_t)ld : 0), kDtype, s); }
     if (center) k::rank1_subtract(X, n_used, ld, mu, sv, s);
   };
 
@@ -538,6 +543,10 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
                                                 std::min<uint64_t>(h.m_global, (uint64_t)n_used));
     h.timings.bytes_per_sweep = (double)h.a_used.nnz * (sizeof(T) + 4) + ((double)h.a_used.rows + 1) * 8 +
                                 (double)n_used * l * sizeof(T) + (double)h.a_used.rows * l * sizeof(T);
+    const bool tiled = h.opt.method == SAPCA_RANDOM && h.tiled_a.valid && h.tiled_at.valid;
+    h.timings.sweep_kernel = !tiled ? 0u : (k::dq_usable(h.tiled_a, 64) && k::dq_usable(h.tiled_at, 64) && h.opt.spmm_variant != 1 ? 2u : 1u);
+    h.timings.sweep_slots_a = tiled ? (uint64_t)h.tiled_a.total_entries : 0;
+    h.timings.sweep_slots_at = tiled ? (uint64_t)h.tiled_at.total_entries : 0;
   }
 }
 

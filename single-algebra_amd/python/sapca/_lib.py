@@ -35,6 +35,7 @@ class Timings(C.Structure):
         ("n_spmm", C.c_uint32), ("n_spmmt", C.c_uint32),
         ("spmm_sweep_ms", C.c_double * 32), ("spmmt_sweep_ms", C.c_double * 32),
         ("bytes_per_sweep", C.c_double), ("lanczos_steps", C.c_uint64),
+        ("sweep_kernel", C.c_uint32), ("reserved0", C.c_uint32), ("sweep_slots_a", C.c_uint64), ("sweep_slots_at", C.c_uint64),
     ]
 
 
@@ -53,7 +54,7 @@ _TYPED = [
 _PLAIN = [
     "sapca_options_default", "sapca_abi_version", "sapca_create", "sapca_destroy", "sapca_last_error",
     "sapca_set_mask", "sapca_get_dims", "sapca_get_total_variance", "sapca_get_mask_index_maps",
-    "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_init_rank",
+    "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_rccl_available", "sapca_comm_init_rank",
     "sapca_comm_set_callback", "sapca_comm_allreduce",
 ]
 EXPORTED_SYMBOLS = _PLAIN + [f"{n}_{s}" for n in _TYPED for s in ("f32", "f64")]

@@ -82,31 +82,35 @@ def host_allreduce_callback(group=None):
 
 def init_comm(estimator, group=None, prefer="rccl", stage_through_host=False):
     """Attach `estimator` (a SparsePCA / MaskedSparsePCA) to the ranks of a torch.distributed group.
-    Returns "rccl" or "torch" (which transport the library will use)."""
+    Returns "rccl" or "torch" (which transport the library will use).
+
+    ncclCommInitRank is collective: a rank that cannot take part must say so BEFORE anyone enters it.  Every rank
+    therefore first reports whether librccl resolves in its process and which device it drives; only if all can and
+    no two ranks of a host share a device does rank 0 create the id.  A failure inside the collective init itself is
+    fatal (the other ranks are still inside it: there is nothing to fall back to)."""
+    import socket
+    import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return "none"
     if prefer == "rccl":
-        ok = [1]
-        uid = [None]
-        if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            if L.load().sapca_comm_unique_id(buf) == L.OK:
-                uid[0] = bytes(buf)
-        dist.broadcast_object_list(uid, src=0, group=group)
-        if uid[0] is not None:
-            try:
+        mine = (bool(L.load().sapca_comm_rccl_available()), socket.gethostname(),
+                torch.cuda.current_device() if torch.cuda.is_available() else -1)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        devices = [(h, d) for _, h, d in everyone]
+        if all(ok for ok, _, _ in everyone) and len(set(devices)) == world and all(d >= 0 for _, d in devices):
+            uid = [None]
+            if rank == 0:
+                buf = (C.c_uint8 * 128)()
+                if L.load().sapca_comm_unique_id(buf) == L.OK:
+                    uid[0] = bytes(buf)
+            dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if uid[0] is not None:   # the same value on every rank: all enter the collective init, or none does
                 estimator.comm_init_rank(world, rank, uid[0])
-            except L.SapcaError:
-                ok[0] = 0
-        else:
-            ok[0] = 0
-        flags = [None] * world
-        dist.all_gather_object(flags, ok[0], group=group)
-        if all(flags):
-            return "rccl"
+                return "rccl"
     estimator.comm_set_callback(world, rank, torch_allreduce_callback(group, stage_through_host))
     return "torch"
 
