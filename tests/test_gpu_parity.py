@@ -358,7 +358,9 @@ def test_properties_at_scale():
     c1 = pca.components_(np.float64)
     np.testing.assert_allclose(c1 @ c1.T, np.eye(k), atol=5e-5)
     t2 = pca.transform(x)
-    assert torch.equal(t1, t2)
+    # a separate transform on caller-owned device arrays does not reuse the fit's preparation (the arrays may have been
+    # edited in between), so it may run another sweep kernel: the same projection to f32 rounding, not bit for bit
+    assert float((t1 - t2).abs().max()) <= 2e-5 * float(t1.abs().max())
     pca_b = _builder(k, 8, 2).build()
     t3 = pca_b.fit_transform(x)
     assert torch.equal(t1, t3) and np.array_equal(pca_b.components_(), pca.components_())      # bitwise reproducible
@@ -382,7 +384,7 @@ def test_properties_at_the_c2_size():
     t1 = pca.fit_transform(x)
     c = pca.components_(np.float64)
     np.testing.assert_allclose(c @ c.T, np.eye(k), atol=5e-5)
-    assert torch.equal(t1, pca.transform(x))
+    assert float((t1 - pca.transform(x)).abs().max()) <= 2e-5 * float(t1.abs().max())   # another sweep kernel: see test_properties_at_scale
     pca_b = _builder(k, p, q).build()
     t3 = pca_b.fit_transform(x)
     assert torch.equal(t1, t3) and np.array_equal(pca_b.components_(), pca.components_())
