@@ -371,23 +371,24 @@ def test_properties_at_scale():
     tc = pc.fit_transform(x).double()
     np.testing.assert_allclose((tc ** 2).sum(0).cpu().numpy() / (m - 1), pc.explained_variance_(np.float64), rtol=2e-3)
 
-def test_properties_at_the_c2_size():
-    """BASELINE's C2 (200k x 20k f32, 1.2e8 stored entries, k=50, p=10, q=4, QR) -- too big for the oracle, so
-    the size-independent properties: orthonormal components, fit_transform == fit + transform, bitwise
-    reproducibility, ratios summing to one (Q4), the variance identity of the CENTERED projection, and the
-    residual check  ||Ac^T u_i - sigma_i v_i|| <= 1e-3 sigma_i  with u_i = Ac v_i / sigma_i computed by the
-    stage-level sweeps on the same resident matrix."""
-    m, n, k, p, q = 200_000, 20_000, 50, 10, 4
-    dev = synth.gapped_csr(m, n, 0.03, k, seed=42, dtype=torch.float32, device="cuda")
+def _properties_of_a_randomized_fit(m, n, density, k, p, q, *, want_kernel=2):
+    """What can be checked without the oracle at BASELINE's full sizes: orthonormal components, fit_transform == fit +
+    transform (to rounding: the separate call may take another sweep kernel), bitwise reproducibility, ratios summing to
+    one (Q4), the variance identity of the CENTERED projection, and the residual check
+    ||Ac^T u_i - sigma_i v_i|| <= 2e-3 sigma_i  with u_i = Ac v_i / sigma_i  through independent torch index arithmetic on
+    the same resident arrays.  `want_kernel`: which sweep the production dispatch must have picked (sapca_timings)."""
+    dev = synth.gapped_csr(m, n, density, k, seed=42, dtype=torch.float32, device="cuda")
     x = sapca.DeviceCsr(*dev, (m, n))
-    pca = _builder(k, p, q).build()
+    pca = _builder(k, p, q).collect_timings(True).build()
     t1 = pca.fit_transform(x)
+    assert int(pca.timings().sweep_kernel) == want_kernel
     c = pca.components_(np.float64)
     np.testing.assert_allclose(c @ c.T, np.eye(k), atol=5e-5)
     assert float((t1 - pca.transform(x)).abs().max()) <= 2e-5 * float(t1.abs().max())   # another sweep kernel: see test_properties_at_scale
     pca_b = _builder(k, p, q).build()
     t3 = pca_b.fit_transform(x)
     assert torch.equal(t1, t3) and np.array_equal(pca_b.components_(), pca.components_())
+    del t1, t3, pca_b
     r = pca.explained_variance_ratio(np.float64)
     assert abs(r.sum() - 1) < 1e-5 and np.all(np.diff(pca.explained_variance_(np.float64)) <= 0)
     pc = _builder(k, p, q).transform_semantics(L.TRANSFORM_CENTERED).build()
@@ -401,12 +402,52 @@ def test_properties_at_the_c2_size():
     rows = torch.repeat_interleave(torch.arange(m, device="cuda"), ptr[1:] - ptr[:-1])
     mean = torch.as_tensor(pc.mean_(np.float64), device="cuda")
     V = torch.as_tensor(pc.components_(np.float64), device="cuda")
+    idx64, val64 = idx.long(), val.double()
     for i in (0, k // 2, k - 1):
         y = tc[:, i]
-        z = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, idx.long(), val.double() * y[rows]) - mean * y.sum()
+        z = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, idx64, val64 * y[rows]) - mean * y.sum()
         resid = (z - sv[i] ** 2 * V[i]).norm().item() / sv[i] ** 2
         assert resid < 2e-3, (i, resid)
 
+
+def test_properties_at_the_c2_size():
+    """BASELINE's C2 (200k x 20k f32, 1.2e8 stored entries, k=50, p=10, q=4, QR) -- too big for the oracle."""
+    _properties_of_a_randomized_fit(200_000, 20_000, 0.03, 50, 10, 4)
+
+
+def test_properties_at_the_c4_size():
+    """BASELINE's C4 on one GPU (1M x 30k f32, 9e8 stored entries, k=50, p=10, q=4, QR): the configuration the north star's
+    roofline target is quoted on; 7.2 GB of CSR, 1024-row blocks on both operators."""
+    _properties_of_a_randomized_fit(1_000_000, 30_000, 0.03, 50, 10, 4)
+
+
+def test_properties_at_the_c5_size():
+    """BASELINE's C5 on one GPU (2M x 50k f32, 1e9 stored entries, 1 % dense, k=100, p=10: l = 110 goes through the
+    64-column tile geometry in two column passes)."""
+    _properties_of_a_randomized_fit(2_000_000, 50_000, 0.01, 100, 10, 4)
+
+
+def test_production_dispatch_against_the_oracle():
+    """The sweep the AUTO dispatch picks for a large operator (spmm_variant = 0, 1.8e7 stored entries: above the
+    staged-sweep floor) against the C restatement of the reference algorithm with the same injected Omega:
+    sigma to 1e-4, subspace angle < 1e-4 (the north-star tolerance), explained-variance ratios to 1e-6."""
+    import orc
+    m, n, density, k, p, q = 30_000, 20_000, 0.03, 50, 10, 4
+    dev = synth.gapped_csr(m, n, density, k, seed=42, dtype=torch.float32, device="cuda")
+    ptr, idx, val = csr_np(dev)
+    om = synth.gaussian_panel(n, k + p, 42).numpy().astype(np.float32)
+    pca = _builder(k, p, q).collect_timings(True).build().set_omega(om)
+    t = pca.fit_transform(sapca.DeviceCsr(*dev, (m, n))).cpu().numpy()
+    assert int(pca.timings().sweep_kernel) == 2            # the DPP-fed quad sweep ran, not the row kernel
+    val = val.astype(np.float64)                           # the oracle in f64: the f32 fit is held to the north-star tolerances
+    rc, comps, sing, ev, mean, tv = orc.randomized_fit(ptr, idx, val, m, n, k, p, q, "QR", True, om.astype(np.float64))
+    assert rc == 0
+    np.testing.assert_allclose(pca.singular_values_(np.float64), sing[:k], rtol=1e-4)
+    assert O.subspace_angle(pca.components_(np.float64), comps[:k].astype(np.float64)) < 1e-4
+    ratio = (sing[:k].astype(np.float64) ** 2) / (sing[:k].astype(np.float64) ** 2).sum()
+    np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), ratio, atol=1e-6)
+    want = orc.transform_sparse(ptr, idx, val, m, n, comps, mean, True)
+    np.testing.assert_allclose(t, want, atol=2e-3 * np.abs(want).max())
 
 
 def test_properties_at_the_c3_size():
