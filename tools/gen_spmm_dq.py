@@ -6,22 +6,32 @@ expressed in HIP C++: accumulators in fixed VGPRs addressed through the VGPR ind
 SRC2 + DST relative), entries broadcast to their 16-lane row group with DPP row_newbcast, the panel tile brought into
 LDS by LDS-DMA (global_load_lds_dwordx4) into two 80 KiB buffers, counted vmcnt / lgkmcnt waits.
 
-Per workgroup (16 waves, one (row block, tile range)):  for every tile t:
-  E0..E2 + descriptor loads of this tile; wait for this wave's LDS-DMA pieces of tile t; s_barrier;
-  LDS-DMA of tile t+1 into the other buffer; L2 prefetch of the next tile's entry stream;
-  chunks of 16 steps: a chunk is one 512-byte coalesced load (lane (g, i) = step i of lane group g), eight groups of
-  two steps each {2 v_add_u32_dpp (address), 2 ds_read_b128, 2 v_mov_b32_dpp (value), 4 v_pk_fma_f32 under the index}.
+Per workgroup (16 waves, one (row block, tile range)), for every tile t of the range:
+  wait for this wave's LDS-DMA pieces of tile t; s_barrier;
+  chunks of 16 steps: a chunk is one 512-byte coalesced load (lane (g, i) = step i of lane group g) into one of three
+  rotating register pairs, then eight groups of two steps each {2 v_add_u32_dpp (address), 2 ds_read_b128,
+  2 v_mov_b32_dpp (value), 4 v_pk_fma_f32 under the index}.  Every chunk also issues, in this order, one LDS-DMA piece
+  of tile t+1 (chunks 0..4; the other LDS buffer), the descriptor load of the next tile (once) and the entry load of
+  the chunk three ahead -- of this tile, or of the first three chunks of the next tile when both tiles have at least
+  three chunks ("linked": the next tile then starts with its entries and descriptors already in registers).
+
+Vector-memory operations return in order, so a wait for a chunk's entries is written as the number of operations
+issued after them: the entries of chunk g were the last operation of chunk slot g-3, hence the count of what slots
+g-2 and g-1 issued (S_N2 + S_N1, kept at run time, 0..3 each); the barrier wait likewise counts what was issued after
+the last LDS-DMA piece (S_ND).  A tile that was not linked loads its first three chunks and descriptors itself and
+waits for everything before its first chunk.
 
 Run:  python3 tools/gen_spmm_dq.py   (writes the header next to the kernel; the header is committed)
 """
 import os
+import re
 import sys
 
 ACC = 56          # first accumulator register; 4 per row slot, + 4 for the trash slot (steps past the end of a stream)
 RG = 8            # row slots per lane group (rows per wave = 4 * RG): set per variant in main()
 TILE_B = 81920    # bytes of one LDS tile buffer (320 panel rows of 256 bytes)
 EB = [(10, 11), (12, 13), (14, 15)]
-VDESC, VLB, VT, VPF = 16, 17, 18, 19
+VDESC, VLB, VT, VDESC2 = 16, 17, 18, 19
 A = [[20, 21], [22, 23]]
 B = [24, 26]
 VINFO = (28, 29)
@@ -29,12 +39,24 @@ W = [[32, 36], [40, 44]]
 # scalars
 S_D0, S_D1, S_REM, S_DL = 36, 37, 38, 39
 S_PTR = 40        # s[40:41] entry stream pointer of the current chunk
-S_DP = 42         # s[42:43] scratch pointer (descriptor / prefetch)
+S_DP = 42         # s[42:43] scratch pointer
 S_T, S_NT, S_CW, S_TABS, S_BUF, S_NCH, S_OFF8 = 44, 45, 46, 47, 48, 49, 50
 S_A, S_B2, S_C, S_D, S_E = 51, 52, 53, 54, 55
 S_INFO = 56       # s[56:57] info pointer of the current 64-tile window
 S_4NCT, S_TLAST, S_DL1 = 58, 59, 60
 S_CI, S_DROW, S_DLDS = 61, 62, 63
+S_N1, S_N2, S_ND, S_NS = 64, 65, 66, 67      # operations issued in the previous / second previous chunk slot, since the last piece, in this slot
+S_LINK, S_PRE, S_BASE = 68, 69, 70           # this tile preloads the next one; this tile was preloaded; entry buffer of its chunk 0
+S_LAST = 71
+S_PTRN = 72       # s[72:73] entry stream pointer of the next tile
+S_DPN = 74        # s[74:75] descriptor pointer of the next tile
+
+_uid = [0]
+
+
+def uid(prefix):
+    _uid[0] += 1
+    return f"{prefix}{_uid[0]}"
 
 
 def grp_a(k, e, L):
@@ -63,8 +85,24 @@ def grp_b(k, L, wait):
         L.append(f"s_lshr_b32 s{sd}, s{sd}, 8")
 
 
+def wait_vmcnt(L, sreg, maxn):
+    """s_waitcnt vmcnt(min(s[sreg], maxn)): the count is a run-time value, the instruction takes an immediate"""
+    end = uid("wv_end")
+    labels = [uid("wv") for _ in range(maxn + 1)]
+    for n in range(maxn, 0, -1):
+        L += [f"s_cmp_ge_u32 s{sreg}, {n}", f"s_cbranch_scc1 {labels[n]}"]
+    L += ["s_waitcnt vmcnt(0)", f"s_branch {end}"]
+    for n in range(1, maxn + 1):
+        L += [f"{labels[n]}:", f"s_waitcnt vmcnt({n})"]
+        if n < maxn:
+            L.append(f"s_branch {end}")
+    L.append(f"{end}:")
+
+
 def dma_piece(L):
     """one 1 KiB LDS-DMA piece of the next tile: 4 panel rows x 256 bytes (lane: row S_DROW-relative, 16 bytes of it)"""
+    skip = uid("dmaskip")
+    L += ["s_bitcmp1_b32 %[mode], 1", f"s_cbranch_scc1 {skip}"]   # diagnostics (SAPCA_DQ_MODE & 2): no refills, timing only
     L.append(f"v_add_u32 v{VT}, s{S_DROW}, %[rowb0]")
     L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
     L.append(f"v_mul_lo_u32 v{VT}, v{VT}, %[stride]")
@@ -72,69 +110,9 @@ def dma_piece(L):
     L.append(f"s_mov_b32 m0, s{S_DLDS}")
     L.append("s_nop 0")
     L.append(f"global_load_lds_dwordx4 v{VT}, %[X]")
+    L.append(f"{skip}:")
     L.append(f"s_add_u32 s{S_DROW}, s{S_DROW}, s{S_4NCT}")
     L.append(f"s_add_u32 s{S_DLDS}, s{S_DLDS}, 0x400")
-
-
-def prefetch_next_stream(L):
-    """L2 prefetch of the next tile's entry stream (lane * 128 bytes, clamped to the stream)"""
-    L += [f"s_add_u32 s{S_A}, s{S_T}, 1", f"s_and_b32 s{S_A}, s{S_A}, 63", f"s_add_u32 s{S_C}, s{S_T}, 1",
-          f"s_cmp_lt_u32 s{S_C}, s{S_NT}", "s_cselect_b32 s%d, s%d, 0" % (S_C, S_A),            # window lane of the next tile, or 0
-          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b32 s{S_C}, s{S_T}, s{S_C}",                    # ... lane 0 = a new window (or no next tile): prefetch the current one
-          f"s_and_b32 s{S_C}, s{S_C}, 63",
-          f"v_readlane_b32 s{S_A}, v{VINFO[0]}, s{S_C}", f"v_readlane_b32 s{S_E}, v{VINFO[1]}, s{S_C}"]
-    ptr_from_off8(L, S_A, S_DP, "ent")
-    L += [f"s_lshl_b32 s{S_E}, s{S_E}, 9", f"s_max_u32 s{S_E}, s{S_E}, 4", f"s_sub_u32 s{S_E}, s{S_E}, 4",
-          f"v_min_u32 v{VT}, s{S_E}, %[l128]", f"global_load_dword v{VPF}, v{VT}, s[{S_DP}:{S_DP + 1}]"]
-
-
-def chunk_body(buf, L, lbl):
-    """Chunk S_CI of the tile (16 steps) from entry buffer `buf` = S_CI mod 3.
-
-    Vector-memory operations return in order, so the wait for this chunk's entries also waits for everything issued
-    before them and is written as a count of what was issued after them.  Per tile, in issue order:
-      E0 E1 E2 descriptor | barrier | chunk 0: prefetch, piece 0, reload 3 | chunk 1: piece 1, reload 4 | ... | leftover pieces
-    (piece c = one of this wave's five LDS-DMA pieces of the NEXT tile, issued in chunk c so that no entry load ever
-    queues behind a burst of them; reload c + 3 only where the stream has such a chunk).  Chunk 0 waits for everything,
-    chunks 1 and 2 for nothing (their entries are older than the descriptor), chunk c >= 3 for
-      [c - 2 < 5] + [c - 1 < 5] + [c + 1 < nch] + [c + 2 < nch]   younger operations."""
-    e = EB[buf]
-    depth = 2
-    L += [f"s_cmp_lt_u32 s{S_CI}, 7", f"s_cbranch_scc1 {lbl}_ws", f"s_cmp_lt_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_ws",
-          "s_waitcnt vmcnt(2)", f"s_branch {lbl}_wz", f"{lbl}_ws:",     # steady state: two reloads behind this chunk's entries
-          f"s_cmp_eq_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_wf", f"s_cmp_lt_u32 s{S_CI}, 3", f"s_cbranch_scc1 {lbl}_wz",
-          f"s_sub_i32 s{S_A}, 7, s{S_CI}", f"s_max_i32 s{S_A}, s{S_A}, 0", f"s_min_i32 s{S_A}, s{S_A}, 2",
-          f"s_sub_u32 s{S_B2}, s{S_REM}, 1", f"s_min_u32 s{S_B2}, s{S_B2}, 2", f"s_add_u32 s{S_A}, s{S_A}, s{S_B2}"]
-    for n in (4, 3, 2, 1):
-        L += [f"s_cmp_lg_u32 s{S_A}, {n}", f"s_cbranch_scc1 {lbl}_w{n - 1}", f"s_waitcnt vmcnt({n})", f"s_branch {lbl}_wz", f"{lbl}_w{n - 1}:"]
-    L += ["s_waitcnt vmcnt(0)", f"s_branch {lbl}_wz", f"{lbl}_wf:", "s_waitcnt vmcnt(0)"]
-    if buf == 0:
-        prefetch_next_stream(L)
-    L += [f"{lbl}_wz:"]
-    L.append(f"s_add_u32 s{S_DL1}, s{S_DL}, 1")
-    L.append(f"v_readlane_b32 s{S_D0}, v{VDESC}, s{S_DL}")
-    L.append(f"v_readlane_b32 s{S_D1}, v{VDESC}, s{S_DL1}")
-    for k in range(depth):
-        grp_a(k, e, L)
-    for k in range(8):
-        ahead = min(depth, 8 - k) - 1
-        grp_b(k, L, 2 * ahead)
-        if k + depth < 8:
-            grp_a(k + depth, e, L)
-            if k + depth == 7:
-                L += [f"s_cmp_ge_u32 s{S_CI}, 5", f"s_cbranch_scc1 {lbl}_nodma"]
-                dma_piece(L)
-                L += [f"{lbl}_nodma:"]
-                # reload: chunk c + 3 exists  <=>  rem > 3   (rem counts the current chunk)
-                L.append(f"s_cmp_le_u32 s{S_REM}, 3")
-                L.append(f"s_cbranch_scc1 {lbl}_norel")
-                L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536 nt")
-                L.append(f"{lbl}_norel:")
-    L.append(f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200")
-    L.append(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
-    L.append(f"s_add_u32 s{S_DL}, s{S_DL}, 2")
-    L.append(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
-    L.append(f"s_add_u32 s{S_CI}, s{S_CI}, 1")
 
 
 def ptr_from_off8(L, s_off8, dst, base):
@@ -146,6 +124,59 @@ def ptr_from_off8(L, s_off8, dst, base):
     L.append(f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}")
 
 
+def desc_ptr(L, s_off8, s_cw, dst):
+    """s[dst:dst+1] = desc + 8 * (off8 / 8 + cw)"""
+    L += [f"s_lshr_b32 s{S_E}, s{s_off8}, 3", f"s_add_u32 s{S_E}, s{S_E}, s{s_cw}", f"s_lshl_b32 s{S_C}, s{S_E}, 3", f"s_lshr_b32 s{S_D}, s{S_E}, 29",
+          f"s_mov_b64 s[{dst}:{dst + 1}], %[desc]", f"s_add_u32 s{dst}, s{dst}, s{S_C}", f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}"]
+
+
+def chunk_body(buf, L):
+    """chunk S_CI of the tile (16 steps) from entry buffer `buf`"""
+    e = EB[buf]
+    depth = 2
+    lbl = f"c{buf}"
+    # ---- wait for this chunk's entries
+    L += [f"s_cmp_lg_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_hist", f"s_cmp_lg_u32 s{S_PRE}, 0", f"s_cbranch_scc1 {lbl}_hist",
+          "s_waitcnt vmcnt(0)", f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0", f"s_branch {lbl}_ready", f"{lbl}_hist:",
+          f"s_add_u32 s{S_A}, s{S_N1}, s{S_N2}"]
+    wait_vmcnt(L, S_A, 6)
+    # a preloaded tile takes its descriptors from the second register (loaded before its first entries: complete by now)
+    L += [f"s_cmp_lg_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_ready", f"s_cmp_eq_u32 s{S_PRE}, 0", f"s_cbranch_scc1 {lbl}_ready",
+          f"v_mov_b32 v{VDESC}, v{VDESC2}", f"{lbl}_ready:"]
+    L.append(f"s_add_u32 s{S_DL1}, s{S_DL}, 1")
+    L.append(f"v_readlane_b32 s{S_D0}, v{VDESC}, s{S_DL}")
+    L.append(f"v_readlane_b32 s{S_D1}, v{VDESC}, s{S_DL1}")
+    for k in range(depth):
+        grp_a(k, e, L)
+    for k in range(8):
+        ahead = min(depth, 8 - k) - 1
+        grp_b(k, L, 2 * ahead)
+        if k + depth < 8:
+            grp_a(k + depth, e, L)
+            if k + depth == 7:      # the buffer's last DPP reads are issued: this slot's memory operations
+                L += [f"s_mov_b32 s{S_NS}, 0", f"s_cmp_ge_u32 s{S_CI}, 5", f"s_cbranch_scc1 {lbl}_nodma"]
+                dma_piece(L)
+                L += [f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_mov_b32 s{S_ND}, 0", f"{lbl}_nodma:"]
+                # rem counts this chunk: the chunk three ahead is in this tile when rem > 3
+                L += [f"s_cmp_le_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_tail",
+                      f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536 nt",
+                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"s_branch {lbl}_issued", f"{lbl}_tail:",
+                      f"s_cmp_eq_u32 s{S_LINK}, 0", f"s_cbranch_scc1 {lbl}_issued"]
+                # linked: chunk 3 - rem of the next tile; its descriptors go first (rem == 3)
+                L += [f"s_cmp_lg_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_nodesc",
+                      f"global_load_dword v{VDESC2}, %[l4], s[{S_DPN}:{S_DPN + 1}]",
+                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"{lbl}_nodesc:",
+                      f"s_sub_u32 s{S_A}, 3, s{S_REM}", f"s_lshl_b32 s{S_A}, s{S_A}, 9", f"v_add_u32 v{VT}, s{S_A}, %[eoff]",
+                      f"global_load_dwordx2 v[{e[0]}:{e[1]}], v{VT}, s[{S_PTRN}:{S_PTRN + 1}] nt",
+                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"{lbl}_issued:",
+                      f"s_mov_b32 s{S_N2}, s{S_N1}", f"s_mov_b32 s{S_N1}, s{S_NS}"]
+    L.append(f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200")
+    L.append(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
+    L.append(f"s_add_u32 s{S_DL}, s{S_DL}, 2")
+    L.append(f"s_sub_u32 s{S_REM}, s{S_REM}, 1")
+    L.append(f"s_add_u32 s{S_CI}, s{S_CI}, 1")
+
+
 def body():
     L = []
     nreg = 4 * RG + 4
@@ -155,7 +186,8 @@ def body():
           "s_set_gpr_idx_off"]
     L += [f"s_mov_b32 s{S_T}, 0", f"s_mov_b32 s{S_NT}, %[ntiles]", f"s_mov_b32 s{S_CW}, %[cw]", f"s_mov_b32 s{S_TABS}, %[t0]",
           f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], 2",
-          f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1"]
+          f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1",
+          f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0", f"s_mov_b32 s{S_ND}, 0", f"s_mov_b32 s{S_PRE}, 0", f"s_mov_b32 s{S_BASE}, 0"]
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
     # first tile: this wave's five pieces into buffer 0, synchronously
@@ -163,35 +195,54 @@ def body():
     dma_piece(L)
     L += [f"s_add_u32 s{S_CI}, s{S_CI}, 1", f"s_cmp_lt_u32 s{S_CI}, 5", "s_cbranch_scc1 13b", "s_waitcnt vmcnt(0)"]
     L += ["10:"]   # ---- tile loop
-    # a new 64-tile window of the info table
+    # a new 64-tile window of the info table (tiles are never linked across windows)
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"s_cmp_lg_u32 s{S_A}, 0", "s_cbranch_scc1 11f", f"s_cmp_eq_u32 s{S_T}, 0",
           "s_cbranch_scc1 11f", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
           f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]", "s_waitcnt vmcnt(0)", "11:"]
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}",
           f"s_min_u32 s{S_NCH}, s{S_NCH}, 32",   # the builder guarantees it; a corrupt table must not turn into an endless loop
-          "s_bitcmp1_b32 %[mode], 0", f"s_cselect_b32 s{S_NCH}, 0, s{S_NCH}"]   # diagnostics (SAPCA_DQ_MODE=1): tiles without compute
+          "s_bitcmp1_b32 %[mode], 0", f"s_cselect_b32 s{S_NCH}, 0, s{S_NCH}"]   # diagnostics (SAPCA_DQ_MODE & 1): tiles without compute
     ptr_from_off8(L, S_OFF8, S_PTR, "ent")
-    # descriptor chunk index = off8 / 8 + cw  (8 bytes each)
-    L += [f"s_lshr_b32 s{S_E}, s{S_OFF8}, 3", f"s_add_u32 s{S_E}, s{S_E}, s{S_CW}", f"s_lshl_b32 s{S_C}, s{S_E}, 3", f"s_lshr_b32 s{S_D}, s{S_E}, 29",
-          f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[desc]", f"s_add_u32 s{S_DP}, s{S_DP}, s{S_C}", f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, s{S_D}"]
+    # link to the next tile?  (same info window, both with at least three chunks)
+    L += [f"s_mov_b32 s{S_LINK}, 0", f"s_add_u32 s{S_B2}, s{S_T}, 1", f"s_cmp_ge_u32 s{S_B2}, s{S_NT}", "s_cbranch_scc1 14f",
+          f"s_and_b32 s{S_B2}, s{S_B2}, 63", f"s_cmp_eq_u32 s{S_B2}, 0", "s_cbranch_scc1 14f", f"s_cmp_lt_u32 s{S_NCH}, 3", "s_cbranch_scc1 14f",
+          f"v_readlane_b32 s{S_LAST}, v{VINFO[1]}, s{S_B2}", f"s_cmp_lt_u32 s{S_LAST}, 3", "s_cbranch_scc1 14f",
+          f"v_readlane_b32 s{S_LAST}, v{VINFO[0]}, s{S_B2}", f"s_mov_b32 s{S_LINK}, 1"]
+    ptr_from_off8(L, S_LAST, S_PTRN, "ent")
+    L += [f"s_add_u32 s{S_B2}, s{S_CW}, 16"]
+    desc_ptr(L, S_LAST, S_B2, S_DPN)
+    L += ["14:"]
+    # a tile that was not preloaded: its first three chunks and its descriptors
+    L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 15f"]
+    desc_ptr(L, S_OFF8, S_CW, S_DP)
     for i, e in enumerate(EB):
         L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i} nt")
     L.append(f"global_load_dword v{VDESC}, %[l4], s[{S_DP}:{S_DP + 1}]")
-    # this wave's pieces of the tile have landed: everything but the four loads above is waited for
-    L += ["s_waitcnt vmcnt(4)", "s_barrier"]
-    # pieces of the next tile go to the other buffer (the last tile reloads itself: harmless, keeps the counts uniform)
+    L += [f"s_add_u32 s{S_ND}, s{S_ND}, 4", f"s_mov_b32 s{S_BASE}, 0", "15:"]
+    # this wave's pieces of the tile have landed: wait for all but what was issued after the last of them
+    wait_vmcnt(L, S_ND, 6)
+    L += ["s_bitcmp1_b32 %[mode], 2", "s_cbranch_scc1 nobar", "s_barrier", "nobar:"]   # (SAPCA_DQ_MODE & 4: timing only)
+    # pieces of the next tile go to the other buffer (the last tile reloads itself: harmless)
     L += [f"s_add_u32 s{S_DROW}, s{S_TABS}, 1", f"s_min_u32 s{S_DROW}, s{S_DROW}, s{S_TLAST}", f"s_sub_u32 s{S_DLDS}, {TILE_B}, s{S_BUF}",
           f"s_add_u32 s{S_DLDS}, s{S_DLDS}, %[wdma]"]
     L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}", f"s_mov_b32 s{S_DL}, 0", f"s_mov_b32 s{S_CI}, 0"]
+    # chunk 0 reads entry buffer S_BASE
+    L += [f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 enter1", f"s_cmp_eq_u32 s{S_BASE}, 2", "s_cbranch_scc1 enter2"]
     L += ["12:"]
     for i in range(3):
+        if i:
+            L.append(f"enter{i}:")
         L += [f"s_cmp_eq_u32 s{S_REM}, 0", "s_cbranch_scc1 19f"]
-        chunk_body(i, L, f"c{i}")
+        chunk_body(i, L)
     L += ["s_branch 12b", "19:"]
-    # pieces the chunks did not issue (fewer than five chunks)
+    # pieces the chunks did not issue (fewer than five chunks): they count as part of the last slot
     L += [f"s_cmp_ge_u32 s{S_CI}, 5", "s_cbranch_scc1 18f", "17:"]
     dma_piece(L)
-    L += [f"s_add_u32 s{S_CI}, s{S_CI}, 1", f"s_cmp_lt_u32 s{S_CI}, 5", "s_cbranch_scc1 17b", "18:"]
+    L += [f"s_add_u32 s{S_N1}, s{S_N1}, 1", f"s_mov_b32 s{S_ND}, 0",
+          f"s_add_u32 s{S_CI}, s{S_CI}, 1", f"s_cmp_lt_u32 s{S_CI}, 5", "s_cbranch_scc1 17b", "18:"]
+    # the next tile starts in the buffer after this tile's last chunk when it was preloaded
+    L += [f"s_add_u32 s{S_BASE}, s{S_BASE}, s{S_NCH}", "16:", f"s_cmp_lt_u32 s{S_BASE}, 3", "s_cbranch_scc1 20f", f"s_sub_u32 s{S_BASE}, s{S_BASE}, 3",
+          "s_branch 16b", "20:", f"s_mov_b32 s{S_PRE}, s{S_LINK}"]
     L += [f"s_add_u32 s{S_T}, s{S_T}, 1", f"s_add_u32 s{S_TABS}, s{S_TABS}, 1", f"s_add_u32 s{S_CW}, s{S_CW}, 16",
           f"s_sub_u32 s{S_BUF}, {TILE_B}, s{S_BUF}", f"s_cmp_lt_u32 s{S_T}, s{S_NT}", "s_cbranch_scc1 10b"]
     L += ["s_waitcnt vmcnt(0)"]
@@ -200,7 +251,6 @@ def body():
 
 def uniq_labels(L):
     """inline asm may be emitted more than once per module: named labels get the %= suffix"""
-    import re
     names = set()
     for ln in L:
         m = re.match(r"^([a-z][a-z0-9_]*):$", ln)
@@ -216,7 +266,7 @@ def uniq_labels(L):
 
 def clobbers():
     v = [f"v{i}" for i in range(10, 48)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 4)]
-    s = [f"s{i}" for i in range(36, 64)]
+    s = [f"s{i}" for i in range(36, 76)]
     return v + s + ["memory", "scc", "m0"]
 
 
@@ -229,6 +279,7 @@ def main():
         out.write(f"#define DQ_ACC_BASE {ACC}\n#define DQ_TILE_BYTES {TILE_B}\n")
         for rg in (8, 16):   # 512-row and 1024-row blocks
             RG = rg
+            _uid[0] = 0
             L = uniq_labels(body())
             out.write(f"#define DQ_MAIN_ASM_{rg} \\\n")
             for ln in L:
