@@ -67,8 +67,9 @@ dq_desc_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __r
   if (lane == 0) {
     uint32_t* w = info + (((int64_t)rb * DQ_WAVES + wave) * nct + t) * 2;
     w[0] = (uint32_t)(s / 8);
-    w[1] = (uint32_t)nch;
-    if (nch > 32) atomicMax(max_nch, nch);
+    const int tail = N - 16 * (nch - 1);                       // steps of the last chunk (1..16), even
+    w[1] = (uint32_t)nch | ((uint32_t)(nch ? (tail + 1) / 2 : 0) << 16);   // .. as two-step groups in the upper half
+    if (nch > 4096) atomicMax(max_nch, nch);
   }
   uint8_t* d = desc + 8 * (s / 64 + cidx * DQ_WAVES + wave);
   int cj[16];
@@ -180,10 +181,9 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   hipLaunchKernelGGL(dq_desc_kernel, dim3((unsigned)nchunks), dim3(DQ_THREADS), 0, s, op.blk_row0, op.nct, op.chunk_off, op.wave_off,
                      reinterpret_cast<const uint16_t*>(op.steps), rg, d_desc, d_info, d_max);
   SAPCA_HIP(hipGetLastError());
-  int max_nch = 0;
-  SAPCA_HIP(hipMemcpyAsync(&max_nch, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
-  SAPCA_HIP(hipStreamSynchronize(s));
-  if (max_nch > 32) return false;   // a wave's stream in one tile above 512 steps: one descriptor load does not cover it
+  // (a wave's stream in one tile may be any length: the sweep reloads its descriptor register every 32 chunks.  The chunk
+  // count shares its table word with the tail length: 16 bits, i.e. 1M steps of one wave in one tile, cannot be reached
+  // with u16 step counts per quad and 16 quads per wave)
   op.dq_desc = d_desc;
   op.dq_info = d_info;
   op.dq = true;

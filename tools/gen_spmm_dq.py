@@ -48,6 +48,7 @@ S_CI, S_DROW, S_DLDS = 61, 62, 63
 S_N1, S_N2, S_ND, S_NS = 64, 65, 66, 67      # operations issued in the previous / second previous chunk slot, since the last piece, in this slot
 S_LINK, S_PRE, S_BASE = 68, 69, 70           # this tile preloads the next one; this tile was preloaded; entry buffer of its chunk 0
 S_LAST = 71
+S_LASTG, S_EARLY = 76, 77                    # valid two-step groups of the tile's last chunk; the chunk was left early
 S_PTRN = 72       # s[72:73] entry stream pointer of the next tile
 S_DPN = 74        # s[74:75] descriptor pointer of the next tile
 
@@ -130,19 +131,28 @@ def desc_ptr(L, s_off8, s_cw, dst):
           f"s_mov_b64 s[{dst}:{dst + 1}], %[desc]", f"s_add_u32 s{dst}, s{dst}, s{S_C}", f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}"]
 
 
-def chunk_body(buf, L):
-    """chunk S_CI of the tile (16 steps) from entry buffer `buf`"""
+def chunk_body(buf, L, O):
+    """chunk S_CI of the tile (16 steps) from entry buffer `buf`.  The steady state (chunk >= 5, more than three chunks
+    left, two reloads behind this chunk's entries) falls through; everything else is out of line (O)."""
     e = EB[buf]
     depth = 2
     lbl = f"c{buf}"
-    # ---- wait for this chunk's entries
-    L += [f"s_cmp_lg_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_hist", f"s_cmp_lg_u32 s{S_PRE}, 0", f"s_cbranch_scc1 {lbl}_hist",
-          "s_waitcnt vmcnt(0)", f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0", f"s_branch {lbl}_ready", f"{lbl}_hist:",
-          f"s_add_u32 s{S_A}, s{S_N1}, s{S_N2}"]
-    wait_vmcnt(L, S_A, 6)
-    # a preloaded tile takes its descriptors from the second register (loaded before its first entries: complete by now)
-    L += [f"s_cmp_lg_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_ready", f"s_cmp_eq_u32 s{S_PRE}, 0", f"s_cbranch_scc1 {lbl}_ready",
-          f"v_mov_b32 v{VDESC}, v{VDESC2}", f"{lbl}_ready:"]
+    # ---- wait for this chunk's entries: s_waitcnt vmcnt(S_N1 + S_N2); chunk 0 of a tile that was not preloaded: vmcnt(0)
+    L += [f"s_cmp_eq_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_first", f"s_add_u32 s{S_A}, s{S_N1}, s{S_N2}", f"s_cmp_lg_u32 s{S_A}, 2",
+          f"s_cbranch_scc1 {lbl}_slow", "s_waitcnt vmcnt(2)", f"{lbl}_ready:"]
+    O += [f"{lbl}_slow:"]
+    wait_vmcnt(O, S_A, 6)
+    O += [f"s_branch {lbl}_ready"]
+    # chunk 0: a preloaded tile takes its descriptors from the second register (loaded before its first entries)
+    O += [f"{lbl}_first:", f"s_cmp_lg_u32 s{S_PRE}, 0", f"s_cbranch_scc1 {lbl}_pre", "s_waitcnt vmcnt(0)", f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0",
+          f"s_branch {lbl}_ready", f"{lbl}_pre:", f"s_add_u32 s{S_A}, s{S_N1}, s{S_N2}"]
+    wait_vmcnt(O, S_A, 6)
+    O += [f"v_mov_b32 v{VDESC}, v{VDESC2}", f"s_branch {lbl}_ready"]
+    # a descriptor register covers 32 chunks: longer streams (dense tiles) reload it, everything waited for
+    L += [f"s_cmp_ge_u32 s{S_DL}, 64", f"s_cbranch_scc1 {lbl}_dreload", f"{lbl}_dok:"]
+    O += [f"{lbl}_dreload:", f"s_add_u32 s{S_DP}, s{S_DP}, 0x100", f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0",
+          f"global_load_dword v{VDESC}, %[l4], s[{S_DP}:{S_DP + 1}]", "s_waitcnt vmcnt(0)", f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0",
+          f"s_mov_b32 s{S_DL}, 0", f"s_branch {lbl}_dok"]
     L.append(f"s_add_u32 s{S_DL1}, s{S_DL}, 1")
     L.append(f"v_readlane_b32 s{S_D0}, v{VDESC}, s{S_DL}")
     L.append(f"v_readlane_b32 s{S_D1}, v{VDESC}, s{S_DL1}")
@@ -154,22 +164,23 @@ def chunk_body(buf, L):
         if k + depth < 8:
             grp_a(k + depth, e, L)
             if k + depth == 7:      # the buffer's last DPP reads are issued: this slot's memory operations
-                L += [f"s_mov_b32 s{S_NS}, 0", f"s_cmp_ge_u32 s{S_CI}, 5", f"s_cbranch_scc1 {lbl}_nodma"]
-                dma_piece(L)
-                L += [f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_mov_b32 s{S_ND}, 0", f"{lbl}_nodma:"]
+                L += [f"s_mov_b32 s{S_NS}, 0", f"s_cmp_lt_u32 s{S_CI}, 5", f"s_cbranch_scc1 {lbl}_dma", f"{lbl}_nodma:"]
+                O += [f"{lbl}_dma:"]
+                dma_piece(O)
+                O += [f"s_mov_b32 s{S_NS}, 1", f"s_mov_b32 s{S_ND}, 0", f"s_branch {lbl}_nodma"]
                 # rem counts this chunk: the chunk three ahead is in this tile when rem > 3
                 L += [f"s_cmp_le_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_tail",
                       f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536 nt",
-                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"s_branch {lbl}_issued", f"{lbl}_tail:",
-                      f"s_cmp_eq_u32 s{S_LINK}, 0", f"s_cbranch_scc1 {lbl}_issued"]
+                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"{lbl}_issued:",
+                      f"s_mov_b32 s{S_N2}, s{S_N1}", f"s_mov_b32 s{S_N1}, s{S_NS}"]
                 # linked: chunk 3 - rem of the next tile; its descriptors go first (rem == 3)
-                L += [f"s_cmp_lg_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_nodesc",
+                O += [f"{lbl}_tail:", f"s_cmp_eq_u32 s{S_LINK}, 0", f"s_cbranch_scc1 {lbl}_issued",
+                      f"s_cmp_lg_u32 s{S_REM}, 3", f"s_cbranch_scc1 {lbl}_nodesc",
                       f"global_load_dword v{VDESC2}, %[l4], s[{S_DPN}:{S_DPN + 1}]",
                       f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"{lbl}_nodesc:",
                       f"s_sub_u32 s{S_A}, 3, s{S_REM}", f"s_lshl_b32 s{S_A}, s{S_A}, 9", f"v_add_u32 v{VT}, s{S_A}, %[eoff]",
                       f"global_load_dwordx2 v[{e[0]}:{e[1]}], v{VT}, s[{S_PTRN}:{S_PTRN + 1}] nt",
-                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"{lbl}_issued:",
-                      f"s_mov_b32 s{S_N2}, s{S_N1}", f"s_mov_b32 s{S_N1}, s{S_NS}"]
+                      f"s_add_u32 s{S_NS}, s{S_NS}, 1", f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"s_branch {lbl}_issued"]
     L.append(f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200")
     L.append(f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0")
     L.append(f"s_add_u32 s{S_DL}, s{S_DL}, 2")
@@ -187,7 +198,7 @@ def body():
     L += [f"s_mov_b32 s{S_T}, 0", f"s_mov_b32 s{S_NT}, %[ntiles]", f"s_mov_b32 s{S_CW}, %[cw]", f"s_mov_b32 s{S_TABS}, %[t0]",
           f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], 2",
           f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1",
-          f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0", f"s_mov_b32 s{S_ND}, 0", f"s_mov_b32 s{S_PRE}, 0", f"s_mov_b32 s{S_BASE}, 0"]
+          f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0", f"s_mov_b32 s{S_ND}, 0", f"s_mov_b32 s{S_PRE}, 0", f"s_mov_b32 s{S_BASE}, 0", f"s_mov_b32 s{S_EARLY}, 0"]
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
     # first tile: this wave's five pieces into buffer 0, synchronously
@@ -200,13 +211,14 @@ def body():
           "s_cbranch_scc1 11f", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
           f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]", "s_waitcnt vmcnt(0)", "11:"]
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}",
-          f"s_min_u32 s{S_NCH}, s{S_NCH}, 32",   # the builder guarantees it; a corrupt table must not turn into an endless loop
+          f"s_lshr_b32 s{S_LASTG}, s{S_NCH}, 16", f"s_and_b32 s{S_NCH}, s{S_NCH}, 0xffff",   # {chunks, valid groups of the last one}
           "s_bitcmp1_b32 %[mode], 0", f"s_cselect_b32 s{S_NCH}, 0, s{S_NCH}"]   # diagnostics (SAPCA_DQ_MODE & 1): tiles without compute
     ptr_from_off8(L, S_OFF8, S_PTR, "ent")
+    desc_ptr(L, S_OFF8, S_CW, S_DP)
     # link to the next tile?  (same info window, both with at least three chunks)
     L += [f"s_mov_b32 s{S_LINK}, 0", f"s_add_u32 s{S_B2}, s{S_T}, 1", f"s_cmp_ge_u32 s{S_B2}, s{S_NT}", "s_cbranch_scc1 14f",
           f"s_and_b32 s{S_B2}, s{S_B2}, 63", f"s_cmp_eq_u32 s{S_B2}, 0", "s_cbranch_scc1 14f", f"s_cmp_lt_u32 s{S_NCH}, 3", "s_cbranch_scc1 14f",
-          f"v_readlane_b32 s{S_LAST}, v{VINFO[1]}, s{S_B2}", f"s_cmp_lt_u32 s{S_LAST}, 3", "s_cbranch_scc1 14f",
+          f"v_readlane_b32 s{S_LAST}, v{VINFO[1]}, s{S_B2}", f"s_and_b32 s{S_LAST}, s{S_LAST}, 0xffff", f"s_cmp_lt_u32 s{S_LAST}, 3", "s_cbranch_scc1 14f",
           f"v_readlane_b32 s{S_LAST}, v{VINFO[0]}, s{S_B2}", f"s_mov_b32 s{S_LINK}, 1"]
     ptr_from_off8(L, S_LAST, S_PTRN, "ent")
     L += [f"s_add_u32 s{S_B2}, s{S_CW}, 16"]
@@ -214,7 +226,6 @@ def body():
     L += ["14:"]
     # a tile that was not preloaded: its first three chunks and its descriptors
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 15f"]
-    desc_ptr(L, S_OFF8, S_CW, S_DP)
     for i, e in enumerate(EB):
         L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i} nt")
     L.append(f"global_load_dword v{VDESC}, %[l4], s[{S_DP}:{S_DP + 1}]")
@@ -229,12 +240,15 @@ def body():
     # chunk 0 reads entry buffer S_BASE
     L += [f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 enter1", f"s_cmp_eq_u32 s{S_BASE}, 2", "s_cbranch_scc1 enter2"]
     L += ["12:"]
+    O = []
     for i in range(3):
         if i:
             L.append(f"enter{i}:")
         L += [f"s_cmp_eq_u32 s{S_REM}, 0", "s_cbranch_scc1 19f"]
-        chunk_body(i, L)
-    L += ["s_branch 12b", "19:"]
+        chunk_body(i, L, O)
+    L += ["s_branch 12b"]
+    L += O            # the rare paths of the three chunk bodies
+    L += ["19:"]
     # pieces the chunks did not issue (fewer than five chunks): they count as part of the last slot
     L += [f"s_cmp_ge_u32 s{S_CI}, 5", "s_cbranch_scc1 18f", "17:"]
     dma_piece(L)
@@ -266,7 +280,7 @@ def uniq_labels(L):
 
 def clobbers():
     v = [f"v{i}" for i in range(10, 48)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 4)]
-    s = [f"s{i}" for i in range(36, 76)]
+    s = [f"s{i}" for i in range(36, 78)]
     return v + s + ["memory", "scc", "m0"]
 
 
