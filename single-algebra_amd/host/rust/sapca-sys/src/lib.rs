@@ -1,4 +1,4 @@
-//! Raw bindings to `include/sapca.h` (ABI version 1).  UNTESTED SOURCE: written against the header,
+//! Raw bindings to `include/sapca.h` (ABI version 2).  UNTESTED SOURCE: written against the header,
 //! never compiled in the build image (no rustc).  One `extern "C"` item per header declaration that
 //! the safe wrapper uses; the `_f64` twins mirror the `_f32` ones.
 #![allow(non_camel_case_types)]
@@ -71,6 +71,9 @@ extern "C" {
                                        col_indices: *const u64, values: *const f64, out: *mut f64) -> c_int;
 
     pub fn sapca_get_dims(h: sapca_handle, k: *mut u64, n_used: *mut u64, n_cols: *mut u64) -> c_int;
+    pub fn sapca_get_mask_index_maps(h: sapca_handle, cols_to_use: *mut u64, cols_cap: usize, orig_to_masked: *mut i64,
+                                     map_cap: usize) -> c_int;
+    pub fn sapca_comm_rccl_available() -> c_int;
     pub fn sapca_get_components_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
     pub fn sapca_get_components_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
     pub fn sapca_get_explained_variance_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;

@@ -1,16 +1,21 @@
 //! Same surface as `single_algebra::dimred::pca` (reference v0.9.2):
-//! `SVDMethod`, `PowerIterationNormalizer`, `SparsePCABuilder`/`SparsePCA`,
-//! `MaskedSparsePCABuilder`/`MaskedSparsePCA`, `fit` / `transform` / `fit_transform` /
+//! `SVDMethod`, `PowerIterationNormalizer`, `SparsePCABuilder<T>`/`SparsePCA<T>`,
+//! `MaskedSparsePCABuilder<T>`/`MaskedSparsePCA<T>`, `fit` / `transform` / `fit_transform` /
 //! `feature_importances` / `explained_variance_ratio` / `cumulative_explained_variance_ratio`,
 //! returning `anyhow::Result` with the reference's messages -- the work happens in libsapca.so.
 //!
-//! UNTESTED SOURCE: written against include/sapca.h, never compiled (no rustc in the build image).
-//! Only the f32 side is spelled out; f64 is the same with the `_f64` symbols.
+//! The reference types are generic over `T: SvdFloat + FloatOpsTS + RealField + ...`
+//! (src/dimred/pca/sparse/mod.rs:33-36, sparse_masked/mod.rs:179-182); in practice T is f32 or f64.
+//! Here T is bounded by the sealed trait `SapcaFloat`, implemented for exactly those two: it carries the
+//! `_f32` / `_f64` entry points of include/sapca.h as associated functions.
+//!
+//! UNTESTED SOURCE: written against include/sapca.h (ABI version 2), never compiled (no rustc in the build image).
 use anyhow::{anyhow, Result};
 use nalgebra_sparse::CsrMatrix;
 use ndarray::{Array1, Array2};
 use sapca_sys as ffi;
 use std::ffi::CStr;
+use std::marker::PhantomData;
 
 #[derive(Debug, Clone, Copy, PartialEq)]
 pub enum PowerIterationNormalizer { QR, LU, None }
@@ -22,6 +27,57 @@ pub enum SVDMethod {
     Random { n_oversamples: usize, n_power_iterations: usize, normalizer: PowerIterationNormalizer },
 }
 impl Default for SVDMethod { fn default() -> Self { Self::Lanczos } }
+
+mod sealed { pub trait Sealed {} impl Sealed for f32 {} impl Sealed for f64 {} }
+
+/// The value types libsapca is built for.  One associated function per typed entry point of the C ABI.
+pub trait SapcaFloat: sealed::Sealed + Copy + Default + num_traits::Zero + 'static {
+    fn to_f64(self) -> f64;
+    unsafe fn fit(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self) -> i32;
+    unsafe fn transform(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self,
+                        out: *mut Self) -> i32;
+    unsafe fn fit_transform(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self,
+                            out: *mut Self) -> i32;
+    unsafe fn feature_importances(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
+    unsafe fn explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
+    unsafe fn cumulative_explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
+    unsafe fn components(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
+    unsafe fn explained_variance(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
+    unsafe fn mean(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
+}
+
+macro_rules! impl_sapca_float {
+    ($t:ty, $fit:ident, $transform:ident, $fit_transform:ident, $fi:ident, $evr:ident, $cevr:ident, $comp:ident, $ev:ident, $mean:ident) => {
+        impl SapcaFloat for $t {
+            fn to_f64(self) -> f64 { self as f64 }
+            unsafe fn fit(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self) -> i32 {
+                ffi::$fit(h, m, n, nnz, ro, ci, v)
+            }
+            unsafe fn transform(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self,
+                                out: *mut Self) -> i32 {
+                ffi::$transform(h, m, n, nnz, ro, ci, v, out)
+            }
+            unsafe fn fit_transform(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64,
+                                    v: *const Self, out: *mut Self) -> i32 {
+                ffi::$fit_transform(h, m, n, nnz, ro, ci, v, out)
+            }
+            unsafe fn feature_importances(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$fi(h, out, cap) }
+            unsafe fn explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$evr(h, out, cap) }
+            unsafe fn cumulative_explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 {
+                ffi::$cevr(h, out, cap)
+            }
+            unsafe fn components(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$comp(h, out, cap) }
+            unsafe fn explained_variance(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$ev(h, out, cap) }
+            unsafe fn mean(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$mean(h, out, cap) }
+        }
+    };
+}
+impl_sapca_float!(f32, sapca_fit_csr_f32, sapca_transform_csr_f32, sapca_fit_transform_csr_f32, sapca_get_feature_importances_f32,
+                  sapca_get_explained_variance_ratio_f32, sapca_get_cumulative_explained_variance_ratio_f32,
+                  sapca_get_components_f32, sapca_get_explained_variance_f32, sapca_get_mean_f32);
+impl_sapca_float!(f64, sapca_fit_csr_f64, sapca_transform_csr_f64, sapca_fit_transform_csr_f64, sapca_get_feature_importances_f64,
+                  sapca_get_explained_variance_ratio_f64, sapca_get_cumulative_explained_variance_ratio_f64,
+                  sapca_get_components_f64, sapca_get_explained_variance_f64, sapca_get_mean_f64);
 
 struct Handle(ffi::sapca_handle);
 impl Drop for Handle { fn drop(&mut self) { unsafe { ffi::sapca_destroy(self.0) } } }
@@ -64,126 +120,165 @@ fn create(n_components: usize, alpha: f64, tolerance: f64, seed: u32, center: bo
     Ok(h)
 }
 
-/// SparsePCA<f32> (sparse/mod.rs:33-359)
-pub struct SparsePCA { h: Handle, n_components: usize }
+/// SparsePCA<T> (sparse/mod.rs:33-359)
+pub struct SparsePCA<T: SapcaFloat> { h: Handle, n_components: usize, _t: PhantomData<T> }
 
-impl SparsePCA {
-    pub fn fit(&mut self, x: &CsrMatrix<f32>) -> Result<&mut Self> {
+impl<T: SapcaFloat> SparsePCA<T> {
+    /// sparse/mod.rs:102-242
+    pub fn fit(&mut self, x: &CsrMatrix<T>) -> Result<&mut Self> {
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
         check(self.h.0, unsafe {
-            ffi::sapca_fit_csr_f32(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64,
-                                   ro.as_ptr() as *const u64, ci.as_ptr() as *const u64, v.as_ptr())
+            T::fit(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+                   ci.as_ptr() as *const u64, v.as_ptr())
         })?;
         Ok(self)
     }
-    pub fn transform(&self, x: &CsrMatrix<f32>) -> Result<Array2<f32>> {
-        let mut out = Array2::<f32>::zeros((x.nrows(), self.n_components));
+    /// sparse/mod.rs:255-285 (the count-weighted projection as written there is the default; see include/sapca.h)
+    pub fn transform(&self, x: &CsrMatrix<T>) -> Result<Array2<T>> {
+        let mut out = Array2::<T>::zeros((x.nrows(), self.n_components));
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
         check(self.h.0, unsafe {
-            ffi::sapca_transform_csr_f32(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64,
-                                         ro.as_ptr() as *const u64, ci.as_ptr() as *const u64, v.as_ptr(),
-                                         out.as_mut_ptr())
+            T::transform(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+                         ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
         })?;
         Ok(out)
     }
-    pub fn fit_transform(&mut self, x: &CsrMatrix<f32>) -> Result<Array2<f32>> {
-        let mut out = Array2::<f32>::zeros((x.nrows(), self.n_components));
+    /// sparse/mod.rs:355-358
+    pub fn fit_transform(&mut self, x: &CsrMatrix<T>) -> Result<Array2<T>> {
+        let mut out = Array2::<T>::zeros((x.nrows(), self.n_components));
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
         check(self.h.0, unsafe {
-            ffi::sapca_fit_transform_csr_f32(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64,
-                                             ro.as_ptr() as *const u64, ci.as_ptr() as *const u64, v.as_ptr(),
-                                             out.as_mut_ptr())
+            T::fit_transform(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+                             ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
         })?;
         Ok(out)
     }
-    fn dims(&self) -> Result<(usize, usize)> {
+    fn dims(&self) -> Result<(usize, usize, usize)> {
         let (mut k, mut nu, mut nc) = (0u64, 0u64, 0u64);
         check(self.h.0, unsafe { ffi::sapca_get_dims(self.h.0, &mut k, &mut nu, &mut nc) })?;
-        Ok((k as usize, nu as usize))
+        Ok((k as usize, nu as usize, nc as usize))
     }
-    pub fn feature_importances(&self) -> Result<Array2<f32>> {
-        let (k, nu) = self.dims()?;
-        let mut out = Array2::<f32>::zeros((k, nu));
-        check(self.h.0, unsafe { ffi::sapca_get_feature_importances_f32(self.h.0, out.as_mut_ptr(), k * nu) })?;
+    /// sparse/mod.rs:295-302
+    pub fn feature_importances(&self) -> Result<Array2<T>> {
+        let (k, nu, _) = self.dims()?;
+        let mut out = Array2::<T>::zeros((k, nu));
+        check(self.h.0, unsafe { T::feature_importances(self.h.0, out.as_mut_ptr(), k * nu) })?;
         Ok(out)
     }
-    pub fn explained_variance_ratio(&self) -> Result<Array1<f32>> {
-        let (k, _) = self.dims()?;
-        let mut out = Array1::<f32>::zeros(k);
-        check(self.h.0, unsafe { ffi::sapca_get_explained_variance_ratio_f32(self.h.0, out.as_mut_ptr(), k) })?;
+    /// sparse/mod.rs:312-322
+    pub fn explained_variance_ratio(&self) -> Result<Array1<T>> {
+        let (k, _, _) = self.dims()?;
+        let mut out = Array1::<T>::zeros(k);
+        check(self.h.0, unsafe { T::explained_variance_ratio(self.h.0, out.as_mut_ptr(), k) })?;
         Ok(out)
     }
-    pub fn cumulative_explained_variance_ratio(&self) -> Result<Array1<f32>> {
-        let (k, _) = self.dims()?;
-        let mut out = Array1::<f32>::zeros(k);
-        check(self.h.0, unsafe { ffi::sapca_get_cumulative_explained_variance_ratio_f32(self.h.0, out.as_mut_ptr(), k) })?;
+    /// sparse/mod.rs:333-343
+    pub fn cumulative_explained_variance_ratio(&self) -> Result<Array1<T>> {
+        let (k, _, _) = self.dims()?;
+        let mut out = Array1::<T>::zeros(k);
+        check(self.h.0, unsafe { T::cumulative_explained_variance_ratio(self.h.0, out.as_mut_ptr(), k) })?;
+        Ok(out)
+    }
+    /// The fields the reference keeps private (sparse/mod.rs:41-43), for callers that need them.
+    pub fn components(&self) -> Result<Array2<T>> {
+        let (k, nu, _) = self.dims()?;
+        let mut out = Array2::<T>::zeros((k, nu));
+        check(self.h.0, unsafe { T::components(self.h.0, out.as_mut_ptr(), k * nu) })?;
+        Ok(out)
+    }
+    pub fn explained_variance(&self) -> Result<Array1<T>> {
+        let (k, _, _) = self.dims()?;
+        let mut out = Array1::<T>::zeros(k);
+        check(self.h.0, unsafe { T::explained_variance(self.h.0, out.as_mut_ptr(), k) })?;
+        Ok(out)
+    }
+    pub fn mean(&self) -> Result<Array1<T>> {
+        let (_, _, nc) = self.dims()?;
+        let mut out = Array1::<T>::zeros(nc);
+        check(self.h.0, unsafe { T::mean(self.h.0, out.as_mut_ptr(), nc) })?;
         Ok(out)
     }
 }
 
-/// SparsePCABuilder<f32> (sparse/mod.rs:375-484; defaults :392-401)
-pub struct SparsePCABuilder {
-    n_components: usize, alpha: f32, tolerance: f32, random_seed: Option<u32>, center: bool, verbose: bool,
-    svdmethod: SVDMethod,
+/// SparsePCABuilder<T> (sparse/mod.rs:375-484; defaults :392-401)
+pub struct SparsePCABuilder<T: SapcaFloat> {
+    n_components: usize, alpha: f64, tolerance: f64, random_seed: Option<u32>, center: bool, verbose: bool,
+    svdmethod: SVDMethod, _t: PhantomData<T>,
 }
-impl Default for SparsePCABuilder {
+impl<T: SapcaFloat> Default for SparsePCABuilder<T> {
     fn default() -> Self {
         Self { n_components: 50, alpha: 1.0, tolerance: 1e-6, random_seed: Some(42), center: true, verbose: false,
-               svdmethod: SVDMethod::default() }
+               svdmethod: SVDMethod::default(), _t: PhantomData }
     }
 }
-impl SparsePCABuilder {
+impl<T: SapcaFloat> SparsePCABuilder<T> {
     pub fn new() -> Self { Self::default() }
     pub fn n_components(mut self, n: usize) -> Self { self.n_components = n; self }
-    pub fn alpha(mut self, a: f32) -> Self { self.alpha = a; self }
-    pub fn tolerance(mut self, t: f32) -> Self { self.tolerance = t; self }
+    pub fn alpha(mut self, a: T) -> Self { self.alpha = a.to_f64(); self }
+    pub fn tolerance(mut self, t: T) -> Self { self.tolerance = t.to_f64(); self }
     pub fn random_seed(mut self, s: u32) -> Self { self.random_seed = Some(s); self }
     pub fn center(mut self, c: bool) -> Self { self.center = c; self }
     pub fn verbose(mut self, v: bool) -> Self { self.verbose = v; self }
     pub fn svd_method(mut self, m: SVDMethod) -> Self { self.svdmethod = m; self }
     /// The reference's `build()` is infallible; creating the GPU handle is not, hence the Result.
-    pub fn build(self) -> Result<SparsePCA> {
-        let h = create(self.n_components, self.alpha as f64, self.tolerance as f64, self.random_seed.unwrap_or(42),
+    pub fn build(self) -> Result<SparsePCA<T>> {
+        let h = create(self.n_components, self.alpha, self.tolerance, self.random_seed.unwrap_or(42),
                        self.center, self.verbose, self.svdmethod, None)?;
-        Ok(SparsePCA { h, n_components: self.n_components })
+        Ok(SparsePCA { h, n_components: self.n_components, _t: PhantomData })
     }
 }
 
-/// MaskedSparsePCA<f32> (sparse_masked/mod.rs:179-620): same calls on a handle that carries the mask.
+/// MaskedSparsePCA<T> (sparse_masked/mod.rs:179-620): same calls on a handle that carries the mask.
 /// The reference rejects ANY mask/column-count mismatch, including an empty mask (:258-262); the C ABI
 /// treats an empty mask as "no mask", so that check lives here.
-pub struct MaskedSparsePCA { inner: SparsePCA, mask_len: usize }
-impl MaskedSparsePCA {
-    fn check_mask(&self, x: &CsrMatrix<f32>) -> Result<()> {
+pub struct MaskedSparsePCA<T: SapcaFloat> { inner: SparsePCA<T>, mask_len: usize }
+impl<T: SapcaFloat> MaskedSparsePCA<T> {
+    fn check_mask(&self, x: &CsrMatrix<T>) -> Result<()> {
         if x.ncols() != self.mask_len {
             return Err(anyhow!("The mask vector length and the number of features (columns) have to be the same!"));
         }
         Ok(())
     }
-    pub fn fit(&mut self, x: &CsrMatrix<f32>) -> Result<&mut Self> { self.check_mask(x)?; self.inner.fit(x)?; Ok(self) }
-    pub fn transform(&self, x: &CsrMatrix<f32>) -> Result<Array2<f32>> { self.check_mask(x)?; self.inner.transform(x) }
-    pub fn fit_transform(&mut self, x: &CsrMatrix<f32>) -> Result<Array2<f32>> { self.check_mask(x)?; self.inner.fit_transform(x) }
-    pub fn feature_importances(&self) -> Result<Array2<f32>> { self.inner.feature_importances() }
-    pub fn explained_variance_ratio(&self) -> Result<Array1<f32>> { self.inner.explained_variance_ratio() }
-    pub fn cumulative_explained_variance_ratio(&self) -> Result<Array1<f32>> { self.inner.cumulative_explained_variance_ratio() }
+    pub fn fit(&mut self, x: &CsrMatrix<T>) -> Result<&mut Self> { self.check_mask(x)?; self.inner.fit(x)?; Ok(self) }
+    pub fn transform(&self, x: &CsrMatrix<T>) -> Result<Array2<T>> { self.check_mask(x)?; self.inner.transform(x) }
+    pub fn fit_transform(&mut self, x: &CsrMatrix<T>) -> Result<Array2<T>> { self.check_mask(x)?; self.inner.fit_transform(x) }
+    pub fn feature_importances(&self) -> Result<Array2<T>> { self.inner.feature_importances() }
+    pub fn explained_variance_ratio(&self) -> Result<Array1<T>> { self.inner.explained_variance_ratio() }
+    pub fn cumulative_explained_variance_ratio(&self) -> Result<Array1<T>> { self.inner.cumulative_explained_variance_ratio() }
+    /// `cols_to_use` and the original -> masked map of sparse_masked/mod.rs:264-271, :462-466 (exact integers)
+    pub fn mask_index_maps(&self) -> Result<(Vec<usize>, Vec<i64>)> {
+        let (_, nu, nc) = self.inner.dims()?;
+        let mut cols = vec![0u64; nu.max(1)];
+        let mut o2m = vec![0i64; nc.max(1)];
+        check(self.inner.h.0, unsafe {
+            ffi::sapca_get_mask_index_maps(self.inner.h.0, cols.as_mut_ptr(), cols.len(), o2m.as_mut_ptr(), o2m.len())
+        })?;
+        cols.truncate(nu);
+        o2m.truncate(nc);
+        Ok((cols.into_iter().map(|c| c as usize).collect(), o2m))
+    }
 }
 
-/// MaskedSparsePCABuilder<f32> (sparse_masked/mod.rs:37-160)
-pub struct MaskedSparsePCABuilder { base: SparsePCABuilder, mask: Vec<bool> }
-impl MaskedSparsePCABuilder {
+/// MaskedSparsePCABuilder<T> (sparse_masked/mod.rs:37-160)
+pub struct MaskedSparsePCABuilder<T: SapcaFloat> { base: SparsePCABuilder<T>, mask: Vec<bool> }
+impl<T: SapcaFloat> MaskedSparsePCABuilder<T> {
     pub fn new() -> Self { Self { base: SparsePCABuilder::default(), mask: Vec::new() } }
     pub fn n_components(mut self, n: usize) -> Self { self.base = self.base.n_components(n); self }
-    pub fn alpha(mut self, a: f32) -> Self { self.base = self.base.alpha(a); self }
-    pub fn tolerance(mut self, t: f32) -> Self { self.base = self.base.tolerance(t); self }
+    pub fn alpha(mut self, a: T) -> Self { self.base = self.base.alpha(a); self }
+    pub fn tolerance(mut self, t: T) -> Self { self.base = self.base.tolerance(t); self }
     pub fn random_seed(mut self, s: u32) -> Self { self.base = self.base.random_seed(s); self }
     pub fn center(mut self, c: bool) -> Self { self.base = self.base.center(c); self }
     pub fn verbose(mut self, v: bool) -> Self { self.base = self.base.verbose(v); self }
     pub fn svd_method(mut self, m: SVDMethod) -> Self { self.base = self.base.svd_method(m); self }
     pub fn mask(mut self, mask: Vec<bool>) -> Self { self.mask = mask; self }
-    pub fn build(self) -> Result<MaskedSparsePCA> {
+    pub fn build(self) -> Result<MaskedSparsePCA<T>> {
         let b = self.base;
-        let h = create(b.n_components, b.alpha as f64, b.tolerance as f64, b.random_seed.unwrap_or(42), b.center,
+        let h = create(b.n_components, b.alpha, b.tolerance, b.random_seed.unwrap_or(42), b.center,
                        b.verbose, b.svdmethod, Some(&self.mask))?;
-        Ok(MaskedSparsePCA { inner: SparsePCA { h, n_components: b.n_components }, mask_len: self.mask.len() })
+        Ok(MaskedSparsePCA { inner: SparsePCA { h, n_components: b.n_components, _t: PhantomData }, mask_len: self.mask.len() })
     }
 }
+
+/// Type aliases for callers that used the two instantiations by name.
+pub type SparsePCAf32 = SparsePCA<f32>;
+pub type SparsePCAf64 = SparsePCA<f64>;

@@ -32,10 +32,22 @@ RG = 8            # row slots per lane group (rows per wave = 4 * RG): set per v
 TILE_B = 81920    # bytes of one LDS tile buffer (320 panel rows of 256 bytes)
 EB = [(10, 11), (12, 13), (14, 15)]
 VDESC, VLB, VT, VDESC2 = 16, 17, 18, 19
+DEPTH = 2         # two-step groups in flight per wave (LDS reads issued ahead of their FMAs); 3 needs 12 more VGPRs
 A = [[20, 21], [22, 23]]
 B = [24, 26]
 VINFO = (28, 29)
 W = [[32, 36], [40, 44]]
+
+
+def set_depth(d, rg):
+    """register map for `d` groups in flight (d = 3 only fits the 8-slot variant: v10..v55 + two registers behind the accumulators)"""
+    global DEPTH, A, B, VINFO, W
+    DEPTH = d
+    if d == 2:
+        A, B, VINFO, W = [[20, 21], [22, 23]], [24, 26], (28, 29), [[32, 36], [40, 44]]
+    else:
+        top = ACC + 4 * rg + 4
+        A, B, VINFO, W = [[20, 21], [22, 23], [24, 25]], [26, 28, 30], (top, top + 1), [[32, 36], [40, 44], [48, 52]]
 # scalars
 S_D0, S_D1, S_REM, S_DL = 36, 37, 38, 39
 S_PTR = 40        # s[40:41] entry stream pointer of the current chunk
@@ -61,7 +73,7 @@ def uid(prefix):
 
 
 def grp_a(k, e, L):
-    p = k & 1
+    p = k % DEPTH
     ex, ey = e
     for t in range(2):
         L.append(f"v_add_u32_dpp v{A[p][t]}, v{ex}, v{VLB} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
@@ -72,7 +84,7 @@ def grp_a(k, e, L):
 
 
 def grp_b(k, L, wait):
-    p = k & 1
+    p = k % DEPTH
     sd = S_D0 if k < 4 else S_D1
     L.append(f"s_waitcnt lgkmcnt({wait})")
     L.append(f"s_set_gpr_idx_on s{sd}, gpr_idx(SRC2,DST)")
@@ -135,7 +147,7 @@ def chunk_body(buf, L, O):
     """chunk S_CI of the tile (16 steps) from entry buffer `buf`.  The steady state (chunk >= 5, more than three chunks
     left, two reloads behind this chunk's entries) falls through; everything else is out of line (O)."""
     e = EB[buf]
-    depth = 2
+    depth = DEPTH
     lbl = f"c{buf}"
     # ---- wait for this chunk's entries: s_waitcnt vmcnt(S_N1 + S_N2); chunk 0 of a tile that was not preloaded: vmcnt(0)
     L += [f"s_cmp_eq_u32 s{S_CI}, 0", f"s_cbranch_scc1 {lbl}_first", f"s_add_u32 s{S_A}, s{S_N1}, s{S_N2}", f"s_cmp_lg_u32 s{S_A}, 2",
@@ -279,7 +291,7 @@ def uniq_labels(L):
 
 
 def clobbers():
-    v = [f"v{i}" for i in range(10, 48)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 4)]
+    v = [f"v{i}" for i in range(10, 48 if DEPTH == 2 else 56)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + (4 if DEPTH == 2 else 6))]
     s = [f"s{i}" for i in range(36, 78)]
     return v + s + ["memory", "scc", "m0"]
 
@@ -291,8 +303,10 @@ def main():
     with open(path, "w") as out:
         out.write("// generated by tools/gen_spmm_dq.py -- do not edit; the generator documents the structure\n")
         out.write(f"#define DQ_ACC_BASE {ACC}\n#define DQ_TILE_BYTES {TILE_B}\n")
+        depth8 = int(os.environ.get("DQ_DEPTH8", "2"))
         for rg in (8, 16):   # 512-row and 1024-row blocks
             RG = rg
+            set_depth(depth8 if rg == 8 else 2, rg)
             _uid[0] = 0
             L = uniq_labels(body())
             out.write(f"#define DQ_MAIN_ASM_{rg} \\\n")
