@@ -110,9 +110,10 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
     unsigned long long ip = (unsigned long long)(info + (((int64_t)rb * DQ_WAVES + wave) * nct + ct0) * 2);
     ip = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ip >> 32)) << 32) |
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ip);
+    const unsigned xlo = (unsigned)(uintptr_t)X, xhi = (unsigned)((uintptr_t)X >> 32);
     const unsigned stride = (unsigned)ldx * 4u, prm1 = (unsigned)(panel_rows - 1), ntiles = (unsigned)(ct1 - ct0), t0 = (unsigned)ct0;
 #define DQ_INPUTS                                                                                                       \
-  [ent] "s"(ent), [desc] "s"(desc), [X] "s"(X), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8), [l4] "v"(l4), \
+  [ent] "s"(ent), [desc] "s"(desc), [xlo] "s"(xlo), [xhi] "s"(xhi), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8), [l4] "v"(l4), \
       [l128] "v"(l128), [col16] "v"(col16), [rowb0] "v"(rowb0), [nct] "s"(nct), [stride] "s"(stride), [prm1] "s"(prm1),      \
       [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [cw] "s"(cw), [mode] "s"(mode)
     if constexpr (RG == 8) {
@@ -190,9 +191,7 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   return true;
 }
 
-bool dq_usable(const TiledOp& op, int ldx) {
-  return op.dq && (ldx == 64 || ldx == 128) && (double)op.cols * ldx * 4.0 < 4294967296.0;
-}
+bool dq_usable(const TiledOp& op, int ldx) { return op.dq && (ldx == 64 || ldx == 128); }
 
 template <int RG>
 static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s) {

@@ -1648,7 +1648,9 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
       nc = op.ldp;
     }
     static const bool force_staged = getenv("SAPCA_SWEEP_STAGED") != nullptr;   // A/B: the staged-entry quad sweep
-    if (op.fmt == 1 && !force_staged && mode == 0 && dq_usable(op, ldx)) {
+    // (blocks of more than 512 rows exist only for the DPP-fed sweep: the switches below do not apply to them)
+    SAPCA_CHECK(op.fmt != 1 || op.block_rows <= 512 || dq_usable(op, ldx), SAPCA_ERR_ARG, "tiled sweep: 1024-row blocks need the DPP-fed sweep");
+    if (op.fmt == 1 && dq_usable(op, ldx) && (op.block_rows > 512 || (!force_staged && mode == 0))) {
       launch_dq(op, Xp, ldx, out, ldo, nc, cv, s);
     } else if (op.fmt == 1) {
       const bool big = op.tile_bytes == Q_TILE_BYTES_BIG;

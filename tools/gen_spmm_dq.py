@@ -32,6 +32,7 @@ RG = 8            # row slots per lane group (rows per wave = 4 * RG): set per v
 TILE_B = 81920    # bytes of one LDS tile buffer (320 panel rows of 256 bytes)
 EB = [(10, 11), (12, 13), (14, 15)]
 VDESC, VLB, VT, VDESC2 = 16, 17, 18, 19
+VA64 = 30         # v[30:31]: 64-bit source address of an LDS-DMA piece
 DEPTH = 2         # two-step groups in flight per wave (LDS reads issued ahead of their FMAs); 3 needs 12 more VGPRs
 A = [[20, 21], [22, 23]]
 B = [24, 26]
@@ -116,13 +117,19 @@ def dma_piece(L):
     """one 1 KiB LDS-DMA piece of the next tile: 4 panel rows x 256 bytes (lane: row S_DROW-relative, 16 bytes of it)"""
     skip = uid("dmaskip")
     L += ["s_bitcmp1_b32 %[mode], 1", f"s_cbranch_scc1 {skip}"]   # diagnostics (SAPCA_DQ_MODE & 2): no refills, timing only
+    # 64-bit source address: panels above 4 GiB exist (10M rows x 128 columns)
     L.append(f"v_add_u32 v{VT}, s{S_DROW}, %[rowb0]")
     L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
-    L.append(f"v_mul_lo_u32 v{VT}, v{VT}, %[stride]")
-    L.append(f"v_add_u32 v{VT}, %[col16], v{VT}")
+    L.append(f"v_mul_hi_u32 v{VA64 + 1}, v{VT}, %[stride]")
+    L.append(f"v_mul_lo_u32 v{VA64}, v{VT}, %[stride]")
+    L.append(f"v_add_co_u32 v{VA64}, vcc, %[col16], v{VA64}")
+    L.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, 0, v{VA64 + 1}, vcc")
+    L.append(f"v_mov_b32 v{VT}, %[xhi]")                      # (an SGPR operand beside vcc would be a second constant-bus read)
+    L.append(f"v_add_co_u32 v{VA64}, vcc, %[xlo], v{VA64}")
+    L.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, v{VT}, v{VA64 + 1}, vcc")
     L.append(f"s_mov_b32 m0, s{S_DLDS}")
     L.append("s_nop 0")
-    L.append(f"global_load_lds_dwordx4 v{VT}, %[X]")
+    L.append(f"global_load_lds_dwordx4 v[{VA64}:{VA64 + 1}], off")
     L.append(f"{skip}:")
     L.append(f"s_add_u32 s{S_DROW}, s{S_DROW}, s{S_4NCT}")
     L.append(f"s_add_u32 s{S_DLDS}, s{S_DLDS}, 0x400")
@@ -293,7 +300,7 @@ def uniq_labels(L):
 def clobbers():
     v = [f"v{i}" for i in range(10, 48 if DEPTH == 2 else 56)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + (4 if DEPTH == 2 else 6))]
     s = [f"s{i}" for i in range(36, 78)]
-    return v + s + ["memory", "scc", "m0"]
+    return v + s + ["memory", "scc", "m0", "vcc"]
 
 
 def main():
