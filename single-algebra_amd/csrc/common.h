@@ -127,6 +127,7 @@ struct TiledOp {
   int slots = 2;            // lane groups per wave the entry stream was padded for
   int fmt = 0;              // 0: two half-waves share a row; 1: "quad", one row per 16-lane group
   int tile_bytes = 0;       // LDS bytes of one panel tile (the entry staging takes the rest of the 160 KiB)
+  int64_t max_chunk = 0;    // most entries of one (row block, tile): the staged-entry kernels need it to fit their LDS staging
   const int32_t* blk_row0 = nullptr;   // [nrb+1] slot positions
   const uint32_t* row_perm = nullptr;  // [rows] slot position -> row (rows sorted by length, longest first); null = identity
   const int64_t* chunk_off = nullptr;  // [nrb*nct+1] entry offsets

@@ -1520,7 +1520,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       fprintf(stderr, "sapca: build_tiled%s rows %lld cols %lld nrb %lld nct %d split %d max_chunk %lld (cap %d) total %lld\n",
               transposed ? " (transposed source)" : "", (long long)op_rows, (long long)op_cols, (long long)nrb, nct, nsplit,
               (long long)max_chunk, stage_cap, (long long)total);
-    if (max_chunk <= stage_cap || (dq_candidate && block_rows > 512)) break;   // 1024-row blocks: no entry staging to fit
+    if (max_chunk <= stage_cap || dq_candidate) break;   // the DPP-fed sweep stages no entries: nothing to fit
     if (tile_bytes == Q_TILE_BYTES_BIG)   // the estimate was too optimistic: take the default split instead of halving the row blocks
       return build_tiled_t<VT>(S, transposed, ldp_elems, op, buf, s, rows_tile_major, packed_rows, false, seg_ready);
     if (attempt == 3 || nrb * 2 > op_rows) return false;  // does not fit: the caller stays on the row kernel
@@ -1584,13 +1584,13 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   }
   SAPCA_HIP(hipGetLastError());
-  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows;
+  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows; op.max_chunk = max_chunk;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
   op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
   if constexpr (f32) {
     const bool dq_ok = dq_build_tables(op, buf, s);
-    if (!dq_ok && block_rows > 512) {   // only the DPP-fed sweep reads 1024-row blocks: the caller stays on the row kernel
+    if (!dq_ok && (block_rows > 512 || max_chunk > stage_cap)) {   // only the DPP-fed sweep reads such operators: the caller stays on the row kernel
       op.valid = false;
       return false;
     }
@@ -1649,8 +1649,9 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
     }
     static const bool force_staged = getenv("SAPCA_SWEEP_STAGED") != nullptr;   // A/B: the staged-entry quad sweep
     // (blocks of more than 512 rows exist only for the DPP-fed sweep: the switches below do not apply to them)
-    SAPCA_CHECK(op.fmt != 1 || op.block_rows <= 512 || dq_usable(op, ldx), SAPCA_ERR_ARG, "tiled sweep: 1024-row blocks need the DPP-fed sweep");
-    if (op.fmt == 1 && dq_usable(op, ldx) && (op.block_rows > 512 || (!force_staged && mode == 0))) {
+    const bool staged_ok = op.block_rows <= 512 && op.max_chunk <= (int64_t)(q_stage_bytes(op.tile_bytes) / 8 - WAVE);
+    SAPCA_CHECK(op.fmt != 1 || staged_ok || dq_usable(op, ldx), SAPCA_ERR_ARG, "tiled sweep: this operator needs the DPP-fed sweep");
+    if (op.fmt == 1 && dq_usable(op, ldx) && (!staged_ok || (!force_staged && mode == 0))) {
       launch_dq(op, Xp, ldx, out, ldo, nc, cv, s);
     } else if (op.fmt == 1) {
       const bool big = op.tile_bytes == Q_TILE_BYTES_BIG;
