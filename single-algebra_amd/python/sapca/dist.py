@@ -86,8 +86,8 @@ def init_comm(estimator, group=None, prefer="rccl", stage_through_host=False):
 
     ncclCommInitRank is collective: a rank that cannot take part must say so BEFORE anyone enters it.  Every rank
     therefore first reports whether librccl resolves in its process and which device it drives; only if all can and
-    no two ranks of a host share a device does rank 0 create the id.  A failure inside the collective init itself is
-    fatal (the other ranks are still inside it: there is nothing to fall back to)."""
+    no two ranks of a host share a device does rank 0 create the id.  After the collective init every rank reports its
+    outcome: RCCL if all succeeded, the torch transport if all failed alike, an error on a split outcome."""
     import socket
     import torch
     import torch.distributed as dist
@@ -109,8 +109,21 @@ def init_comm(estimator, group=None, prefer="rccl", stage_through_host=False):
                     uid[0] = bytes(buf)
             dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             if uid[0] is not None:   # the same value on every rank: all enter the collective init, or none does
-                estimator.comm_init_rank(world, rank, uid[0])
-                return "rccl"
+                try:
+                    estimator.comm_init_rank(world, rank, uid[0])
+                    err = None
+                except L.SapcaError as e:
+                    err = str(e)
+                # every rank is out of the collective call at this point (a rank still inside it would hang either way):
+                # all succeeded -> RCCL; all failed alike -> the torch transport; a split outcome cannot be repaired
+                outcome = [None] * world
+                dist.all_gather_object(outcome, err, group=group)
+                if all(o is None for o in outcome):
+                    return "rccl"
+                if any(o is None for o in outcome):
+                    raise RuntimeError(f"ncclCommInitRank succeeded on some ranks only: {outcome}")
+                if rank == 0:
+                    print(f"sapca: RCCL initialisation failed on every rank ({outcome[0]}); using torch.distributed", flush=True)
     estimator.comm_set_callback(world, rank, torch_allreduce_callback(group, stage_through_host))
     return "torch"
 
