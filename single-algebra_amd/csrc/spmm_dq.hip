@@ -111,11 +111,12 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
     ip = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ip >> 32)) << 32) |
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ip);
     const unsigned xlo = (unsigned)(uintptr_t)X, xhi = (unsigned)((uintptr_t)X >> 32);
+    const unsigned voff = (unsigned)g * (unsigned)nct * ((unsigned)ldx * 4u) + col16;   // lane part of an LDS-DMA piece's source address
     const unsigned stride = (unsigned)ldx * 4u, prm1 = (unsigned)(panel_rows - 1), ntiles = (unsigned)(ct1 - ct0), t0 = (unsigned)ct0;
 #define DQ_INPUTS                                                                                                       \
   [ent] "s"(ent), [desc] "s"(desc), [xlo] "s"(xlo), [xhi] "s"(xhi), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8), [l4] "v"(l4), \
       [l128] "v"(l128), [col16] "v"(col16), [rowb0] "v"(rowb0), [nct] "s"(nct), [stride] "s"(stride), [prm1] "s"(prm1),      \
-      [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [cw] "s"(cw), [mode] "s"(mode)
+      [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [cw] "s"(cw), [mode] "s"(mode), [voff] "v"(voff)
     if constexpr (RG == 8) {
       asm volatile(DQ_MAIN_ASM_8
                    : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)

@@ -62,6 +62,8 @@ S_N1, S_N2, S_ND, S_NS = 64, 65, 66, 67      # operations issued in the previous
 S_LINK, S_PRE, S_BASE = 68, 69, 70           # this tile preloads the next one; this tile was preloaded; entry buffer of its chunk 0
 S_LAST = 71
 S_LASTG, S_EARLY = 76, 77                    # valid two-step groups of the tile's last chunk; the chunk was left early
+S_DADDR = 78      # s[78:79] scalar source address of the next LDS-DMA piece
+S_PSTEP, S_LIM, S_ROWBW = 80, 81, 82         # bytes between pieces; last S_DROW whose four rows are all inside the panel; 20 * wave * nct
 S_PTRN = 72       # s[72:73] entry stream pointer of the next tile
 S_DPN = 74        # s[74:75] descriptor pointer of the next tile
 
@@ -73,9 +75,21 @@ def uid(prefix):
     return f"{prefix}{_uid[0]}"
 
 
+B64 = os.environ.get("DQ_B64", "0") != "0"   # experiment (1.5 % slower at C2): one 64-bit row_newbcast move per step + a plain add
+P64 = [[20, 22], [24, 26]]                      # .. into these even-aligned pairs: lo becomes the LDS address, hi is the value
+
+
 def grp_a(k, e, L):
     p = k % DEPTH
     ex, ey = e
+    if B64 and DEPTH == 2:
+        for t in range(2):
+            L.append(f"v_mov_b64_dpp v[{P64[p][t]}:{P64[p][t] + 1}], v[{ex}:{ey}] row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+        for t in range(2):
+            L.append(f"v_add_u32 v{P64[p][t]}, v{P64[p][t]}, v{VLB}")
+        for t in range(2):
+            L.append(f"ds_read_b128 v[{W[p][t]}:{W[p][t] + 3}], v{P64[p][t]}")
+        return
     for t in range(2):
         L.append(f"v_add_u32_dpp v{A[p][t]}, v{ex}, v{VLB} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
     for t in range(2):
@@ -91,9 +105,12 @@ def grp_b(k, L, wait):
     L.append(f"s_set_gpr_idx_on s{sd}, gpr_idx(SRC2,DST)")
     for t in range(2):
         w = W[p][t]
-        sel = "op_sel_hi:[1,0,1]" if t == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]"
-        L.append(f"v_pk_fma_f32 v[{ACC}:{ACC + 1}], v[{w}:{w + 1}], v[{B[p]}:{B[p] + 1}], v[{ACC}:{ACC + 1}] {sel}")
-        L.append(f"v_pk_fma_f32 v[{ACC + 2}:{ACC + 3}], v[{w + 2}:{w + 3}], v[{B[p]}:{B[p] + 1}], v[{ACC + 2}:{ACC + 3}] {sel}")
+        if B64 and DEPTH == 2:
+            b, sel = P64[p][t], "op_sel:[0,1,0] op_sel_hi:[1,1,1]"    # the value is the pair's upper half
+        else:
+            b, sel = B[p], ("op_sel_hi:[1,0,1]" if t == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+        L.append(f"v_pk_fma_f32 v[{ACC}:{ACC + 1}], v[{w}:{w + 1}], v[{b}:{b + 1}], v[{ACC}:{ACC + 1}] {sel}")
+        L.append(f"v_pk_fma_f32 v[{ACC + 2}:{ACC + 3}], v[{w + 2}:{w + 3}], v[{b}:{b + 1}], v[{ACC + 2}:{ACC + 3}] {sel}")
     L.append("s_set_gpr_idx_off")
     if k not in (3, 7):
         L.append(f"s_lshr_b32 s{sd}, s{sd}, 8")
@@ -113,26 +130,49 @@ def wait_vmcnt(L, sreg, maxn):
     L.append(f"{end}:")
 
 
-def dma_piece(L):
-    """one 1 KiB LDS-DMA piece of the next tile: 4 panel rows x 256 bytes (lane: row S_DROW-relative, 16 bytes of it)"""
-    skip = uid("dmaskip")
+def dma_tile_setup(L):
+    """scalar source address of this wave's first piece of tile S_DROW: X + (S_DROW + 20 * wave * nct) * stride"""
+    L += [f"s_add_u32 s{S_A}, s{S_DROW}, s{S_ROWBW}",
+          f"s_mul_hi_u32 s{S_DADDR + 1}, s{S_A}, %[stride]", f"s_mul_i32 s{S_DADDR}, s{S_A}, %[stride]",
+          f"s_add_u32 s{S_DADDR}, s{S_DADDR}, %[xlo]", f"s_addc_u32 s{S_DADDR + 1}, s{S_DADDR + 1}, %[xhi]"]
+
+
+def dma_piece(L, O=None):
+    """one 1 KiB LDS-DMA piece of the next tile: 4 panel rows x 256 bytes (lane group g: row S_DROW + (20 wave + g) nct,
+    lane: 16 bytes of it).  The source address is scalar (s[S_DADDR] + the lane's constant offset) unless one of the four
+    rows lies past the panel's end: those pieces (the last one or two of a tile) clamp the row per lane."""
+    skip, slow, done = uid("dmaskip"), uid("dmaslow"), uid("dmadone")
     L += ["s_bitcmp1_b32 %[mode], 1", f"s_cbranch_scc1 {skip}"]   # diagnostics (SAPCA_DQ_MODE & 2): no refills, timing only
-    # 64-bit source address: panels above 4 GiB exist (10M rows x 128 columns)
-    L.append(f"v_add_u32 v{VT}, s{S_DROW}, %[rowb0]")
-    L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
-    L.append(f"v_mul_hi_u32 v{VA64 + 1}, v{VT}, %[stride]")
-    L.append(f"v_mul_lo_u32 v{VA64}, v{VT}, %[stride]")
-    L.append(f"v_add_co_u32 v{VA64}, vcc, %[col16], v{VA64}")
-    L.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, 0, v{VA64 + 1}, vcc")
-    L.append(f"v_mov_b32 v{VT}, %[xhi]")                      # (an SGPR operand beside vcc would be a second constant-bus read)
-    L.append(f"v_add_co_u32 v{VA64}, vcc, %[xlo], v{VA64}")
-    L.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, v{VT}, v{VA64 + 1}, vcc")
+    L += [f"s_cmp_gt_i32 s{S_DROW}, s{S_LIM}", f"s_cbranch_scc1 {slow}"]
     L.append(f"s_mov_b32 m0, s{S_DLDS}")
     L.append("s_nop 0")
-    L.append(f"global_load_lds_dwordx4 v[{VA64}:{VA64 + 1}], off")
+    L.append(f"global_load_lds_dwordx4 %[voff], s[{S_DADDR}:{S_DADDR + 1}]")
+    S = [] if O is None else O
+    if O is None:
+        L.append(f"s_branch {done}")
+    S.append(f"{slow}:")
+    # 64-bit per-lane source address: panels above 4 GiB exist (10M rows x 128 columns)
+    S.append(f"v_add_u32 v{VT}, s{S_DROW}, %[rowb0]")
+    S.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
+    S.append(f"v_mul_hi_u32 v{VA64 + 1}, v{VT}, %[stride]")
+    S.append(f"v_mul_lo_u32 v{VA64}, v{VT}, %[stride]")
+    S.append(f"v_add_co_u32 v{VA64}, vcc, %[col16], v{VA64}")
+    S.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, 0, v{VA64 + 1}, vcc")
+    S.append(f"v_mov_b32 v{VT}, %[xhi]")                      # (an SGPR operand beside vcc would be a second constant-bus read)
+    S.append(f"v_add_co_u32 v{VA64}, vcc, %[xlo], v{VA64}")
+    S.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, v{VT}, v{VA64 + 1}, vcc")
+    S.append(f"s_mov_b32 m0, s{S_DLDS}")
+    S.append("s_nop 0")
+    S.append(f"global_load_lds_dwordx4 v[{VA64}:{VA64 + 1}], off")
+    if O is None:
+        L += S
+    else:
+        S.append(f"s_branch {done}")
+    L.append(f"{done}:")
     L.append(f"{skip}:")
     L.append(f"s_add_u32 s{S_DROW}, s{S_DROW}, s{S_4NCT}")
     L.append(f"s_add_u32 s{S_DLDS}, s{S_DLDS}, 0x400")
+    L += [f"s_add_u32 s{S_DADDR}, s{S_DADDR}, s{S_PSTEP}", f"s_addc_u32 s{S_DADDR + 1}, s{S_DADDR + 1}, 0"]
 
 
 def ptr_from_off8(L, s_off8, dst, base):
@@ -218,10 +258,14 @@ def body():
           f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], 2",
           f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1",
           f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0", f"s_mov_b32 s{S_ND}, 0", f"s_mov_b32 s{S_PRE}, 0", f"s_mov_b32 s{S_BASE}, 0", f"s_mov_b32 s{S_EARLY}, 0"]
+    L += [f"v_readfirstlane_b32 s{S_ROWBW}, %[rowb0]", f"s_mul_i32 s{S_PSTEP}, s{S_4NCT}, %[stride]",
+          f"s_mul_i32 s{S_LIM}, %[nct], 3", f"s_add_u32 s{S_LIM}, s{S_LIM}, s{S_ROWBW}", f"s_sub_u32 s{S_LIM}, %[prm1], s{S_LIM}"]
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
     # first tile: this wave's five pieces into buffer 0, synchronously
-    L += [f"s_mov_b32 s{S_DROW}, s{S_TABS}", f"s_mov_b32 s{S_DLDS}, %[wdma]", f"s_mov_b32 s{S_CI}, 0", "13:"]
+    L += [f"s_mov_b32 s{S_DROW}, s{S_TABS}", f"s_mov_b32 s{S_DLDS}, %[wdma]", f"s_mov_b32 s{S_CI}, 0"]
+    dma_tile_setup(L)
+    L += ["13:"]
     dma_piece(L)
     L += [f"s_add_u32 s{S_CI}, s{S_CI}, 1", f"s_cmp_lt_u32 s{S_CI}, 5", "s_cbranch_scc1 13b", "s_waitcnt vmcnt(0)"]
     L += ["10:"]   # ---- tile loop
@@ -255,6 +299,7 @@ def body():
     # pieces of the next tile go to the other buffer (the last tile reloads itself: harmless)
     L += [f"s_add_u32 s{S_DROW}, s{S_TABS}, 1", f"s_min_u32 s{S_DROW}, s{S_DROW}, s{S_TLAST}", f"s_sub_u32 s{S_DLDS}, {TILE_B}, s{S_BUF}",
           f"s_add_u32 s{S_DLDS}, s{S_DLDS}, %[wdma]"]
+    dma_tile_setup(L)
     L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}", f"s_mov_b32 s{S_DL}, 0", f"s_mov_b32 s{S_CI}, 0"]
     # chunk 0 reads entry buffer S_BASE
     L += [f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 enter1", f"s_cmp_eq_u32 s{S_BASE}, 2", "s_cbranch_scc1 enter2"]
@@ -299,7 +344,7 @@ def uniq_labels(L):
 
 def clobbers():
     v = [f"v{i}" for i in range(10, 48 if DEPTH == 2 else 56)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + (4 if DEPTH == 2 else 6))]
-    s = [f"s{i}" for i in range(36, 78)]
+    s = [f"s{i}" for i in range(36, 83)]
     return v + s + ["memory", "scc", "m0", "vcc"]
 
 
