@@ -74,9 +74,19 @@ bool narrow_chunk(const uint64_t* in, int32_t* out, size_t count, uint64_t n, un
 }
 }  // namespace
 
+// side stream shared by prepare() (A's format beside the transposition) and upload() (statistics beside the DMA)
+void ensure_side_stream(sapca_handle h) {
+  if (h->stream2) return;
+  SAPCA_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  SAPCA_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  SAPCA_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+}
+
+// with_stats: the matrix is about to be fitted -- accumulate its column statistics (R1/R2 and the per-column counts)
+// on the side stream, chunk by chunk behind the DMA, so prepare() finds them ready
 template <typename T>
 CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* row_offsets,
-                  const uint64_t* col_indices, const T* values) {
+                  const uint64_t* col_indices, const T* values, bool with_stats = false) {
   SAPCA_CHECK(row_offsets != nullptr && (nnz == 0 || (col_indices && values)), SAPCA_ERR_ARG, "null CSR array");
   SAPCA_CHECK(row_offsets[0] == 0 && row_offsets[m] == nnz, SAPCA_ERR_ARG, "row_offsets do not span [0, nnz]");
   {   // with monotone offsets and in-range columns (checked below) no kernel can leave the arrays
@@ -87,6 +97,7 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
   SAPCA_CHECK(n < (1ull << 31) && m < (1ull << 31), SAPCA_ERR_ARG, "more than 2^31-1 rows or columns is not supported");
   hipStream_t s = h->stream;
   h->prep_key.valid = false;  // the upload buffers are about to hold a different matrix
+  h->up_stats.valid = false;
   auto t0 = std::chrono::steady_clock::now();
   int64_t* d_ptr = h->in_ptr.as<int64_t>(m + 1);
   int32_t* d_idx = h->in_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
@@ -96,7 +107,8 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
   SAPCA_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
   SAPCA_HIP(hipMemcpyAsync(d64, row_offsets, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
   static const bool on_device = getenv("SAPCA_UPLOAD_NARROW_ON_DEVICE") != nullptr;   // the first version: ship u64, narrow on the GPU
-  bool bad_host = false;
+  bool bad_host = false, stats_here = false;
+  void* stats_work = nullptr;
   if (nnz == 0 || !on_device) sapca::k::narrow_indices(d64, d64, (int64_t)m, 0, (int64_t)n, d_ptr, d_idx, flag, s);   // row offsets only
   if (nnz) {
     SAPCA_HIP(hipMemcpyAsync(d_val, values, nnz * sizeof(T), hipMemcpyHostToDevice, s));
@@ -111,6 +123,16 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
         h->up_stage[b].ensure(chunk * sizeof(int32_t));
         if (!h->up_done[b]) SAPCA_HIP(hipEventCreateWithFlags(&h->up_done[b], hipEventDisableTiming));
       }
+      static const bool stats_off = getenv("SAPCA_UPLOAD_STATS_OFF") != nullptr;
+      stats_here = with_stats && !stats_off && n > 0 && sapca::k::exact_colstats_bytes<T>((int64_t)n) <= ((size_t)1 << 30);
+      if (stats_here) {
+        ensure_side_stream(h);
+        stats_work = h->up_stats.work.ensure(sapca::k::exact_colstats_bytes<T>((int64_t)n));
+        sapca::k::exact_colstats_reset<T>(stats_work, (int64_t)n, h->stream2);
+        SAPCA_HIP(hipEventRecord(h->ev_fork, s));                        // row offsets and values are on the device
+        SAPCA_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        sapca::k::exact_colstats_scan_values<T>(d_val, (int64_t)nnz, (int64_t)n, stats_work, h->stream2);
+      }
       bool used[2] = {false, false};
       int b = 0;
       for (size_t off = 0; off < nnz; off += chunk, b ^= 1) {
@@ -121,13 +143,34 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
         SAPCA_HIP(hipMemcpyAsync(d_idx + off, stage, cnt * sizeof(int32_t), hipMemcpyHostToDevice, s));
         SAPCA_HIP(hipEventRecord(h->up_done[b], s));
         used[b] = true;
+        if (stats_here) {   // this chunk's entries (the values all went first) feed the accumulators while the next chunk crosses
+          SAPCA_HIP(hipStreamWaitEvent(h->stream2, h->up_done[b], 0));
+          const uint64_t* ro_end = row_offsets + m + 1;
+          const int64_t r_lo = (int64_t)(std::upper_bound(row_offsets, ro_end, (uint64_t)off) - row_offsets) - 1;
+          const int64_t r_hi = (int64_t)(std::lower_bound(row_offsets, ro_end, (uint64_t)(off + cnt)) - row_offsets);
+          sapca::k::exact_colstats_add<T>(d_ptr, d_idx, d_val, r_lo, std::min<int64_t>(r_hi, (int64_t)m), (int64_t)off,
+                                          (int64_t)(off + cnt), (int64_t)n, stats_work, h->stream2);
+        }
       }
     }
   }
   int bad = 0;
+  if (stats_here) {
+    // the last chunk's share and the final rounding stay in flight behind this call: their consumer (prepare(), the column
+    // statistics helper) waits for `up_stats_done` and reads the "a value was inf/nan" flag then
+    double* out = h->up_stats.out.as<double>(3 * n);
+    int* nonfinite = static_cast<int*>(h->up_stats.flag.ensure(sizeof(int)));
+    sapca::k::exact_colstats_finish<T>(stats_work, (int64_t)n, out, nonfinite, h->stream2);
+    if (!h->up_stats_done) SAPCA_HIP(hipEventCreateWithFlags(&h->up_stats_done, hipEventDisableTiming));
+    SAPCA_HIP(hipEventRecord(h->up_stats_done, h->stream2));
+  }
   SAPCA_HIP(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s));
   SAPCA_HIP(hipStreamSynchronize(s));
   SAPCA_CHECK(bad == 0 && !bad_host, SAPCA_ERR_ARG, "column index out of range");
+  if (stats_here) {
+    h->up_stats.m = m; h->up_stats.n = n; h->up_stats.nnz = nnz; h->up_stats.dtype = sizeof(T) == 4 ? 0 : 1;
+    h->up_stats.valid = true;
+  }
   h->timings.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   CsrView<T> v;
   v.rows = (int64_t)m; v.cols = (int64_t)n; v.nnz = (int64_t)nnz;
@@ -153,7 +196,7 @@ void download_out(sapca_handle h, const T* d, T* out, size_t count) {
 template <typename T>
 sapca_status fit_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci,
                       const T* v) {
-  return guarded(h, [&] { Engine<T>::fit(*h, upload<T>(h, m, n, nnz, ro, ci, v)); });
+  return guarded(h, [&] { Engine<T>::fit(*h, upload<T>(h, m, n, nnz, ro, ci, v, true)); });
 }
 
 template <typename T>
@@ -166,7 +209,7 @@ sapca_status transform_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz
         throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
       if (!h->fitted) throw Error(SAPCA_ERR_NOT_FITTED, "Must be fitted before transform!");
     }
-    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v, fit_first);
     if (fit_first) Engine<T>::fit(*h, A);
     T* d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * h->k, 1));
     Engine<T>::transform(*h, A, d_out);
@@ -247,19 +290,24 @@ template <typename T>
 sapca_status colstats_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro,
                            const uint64_t* ci, const T* v, T* sum_col, T* sum_sq, uint64_t* cnt) {
   return guarded(h, [&] {
-    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v, true);
     hipStream_t s = h->stream;
-    int64_t* at_ptr = h->at_ptr.as<int64_t>(n + 1);
-    int32_t* at_idx = h->at_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
-    T* at_val = h->at_val.as<T>(std::max<uint64_t>(nnz, 1));
-    sapca::k::transpose_csr(A, at_ptr, at_idx, at_val, h->scratch, s);
-    CsrView<T> At;
-    At.rows = (int64_t)n; At.cols = (int64_t)m; At.nnz = (int64_t)nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
-    double* d = h->stats.as<double>(3 * n + 1);
-    sapca::k::row_sums(At, d, d + n, s);
-    sapca::k::row_lengths_f64(at_ptr, (int64_t)n, d + 2 * n, s);
     std::vector<double> host(3 * n);
-    download_out(h, d, host.data(), 3 * n);
+    if (h->up_stats.valid) SAPCA_HIP(hipEventSynchronize(h->up_stats_done));
+    if (h->up_stats.valid && *static_cast<const int*>(h->up_stats.flag.p) == 0) {   // gathered behind the DMA (exact sums, rounded once)
+      download_out(h, h->up_stats.out.ptr<double>(), host.data(), 3 * n);
+    } else {                   // row sums of A^T: what prepare() runs on device-resident input
+      int64_t* at_ptr = h->at_ptr.as<int64_t>(n + 1);
+      int32_t* at_idx = h->at_idx.as<int32_t>(std::max<uint64_t>(nnz, 1));
+      T* at_val = h->at_val.as<T>(std::max<uint64_t>(nnz, 1));
+      sapca::k::transpose_csr(A, at_ptr, at_idx, at_val, h->scratch, s);
+      CsrView<T> At;
+      At.rows = (int64_t)n; At.cols = (int64_t)m; At.nnz = (int64_t)nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
+      double* d = h->stats.as<double>(3 * n + 1);
+      sapca::k::row_sums(At, d, d + n, s);
+      sapca::k::row_lengths_f64(at_ptr, (int64_t)n, d + 2 * n, s);
+      download_out(h, d, host.data(), 3 * n);
+    }
     for (uint64_t j = 0; j < n; ++j) {
       if (sum_col) sum_col[j] = (T)host[j];
       if (sum_sq) sum_sq[j] = (T)host[n + j];
@@ -274,7 +322,7 @@ sapca_status upload_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, c
                          const T* v, const int64_t** d_ptr, const int32_t** d_idx, T** d_val) {
   return guarded(h, [&] {
     SAPCA_CHECK(d_ptr && d_idx && d_val, SAPCA_ERR_ARG, "null output pointer");
-    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
+    CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v, true);   // (a later fit of the untouched arrays finds its statistics ready)
     *d_ptr = A.ptr;
     *d_idx = A.idx;
     *d_val = const_cast<T*>(A.val);
@@ -293,6 +341,7 @@ sapca_status normalize_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t n
     CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
     if (want == 0 || nnz == 0) return;
     h->prep_key.valid = false;   // the values change under any cached preparation
+    h->up_stats.valid = false;   // .. and under the statistics gathered at upload
     double* d = h->stats.as<double>(2 * want);
     SAPCA_HIP(hipMemcpyAsync(d, sums, want * sizeof(double), hipMemcpyHostToDevice, h->stream));
     sapca::k::normalize_csr(A, v, d, target, direction == 1, d + want, h->stream);
@@ -305,6 +354,7 @@ sapca_status log1p_device(sapca_handle h, uint64_t nnz, T* v) {
   return guarded(h, [&] {
     SAPCA_CHECK(v != nullptr || nnz == 0, SAPCA_ERR_ARG, "null values");
     h->prep_key.valid = false;
+    h->up_stats.valid = false;
     sapca::k::log1p_values(v, (int64_t)nnz, h->stream);
     SAPCA_HIP(hipStreamSynchronize(h->stream));
   });
@@ -518,6 +568,7 @@ void sapca_destroy(sapca_handle h) {
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->up_stats_done) (void)hipEventDestroy(h->up_stats_done);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

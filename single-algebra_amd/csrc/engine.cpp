@@ -158,24 +158,39 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   // R1/R2 (csr.rs:259-312, 558-608) as row sums of A^T, plus the per-column stored-entry count.
   std::vector<double> sums((size_t)2 * n + 1, 0.0);
-  {
+  // a host matrix that came through upload() brought its statistics along (gathered behind the DMA, exact sums)
+  const bool from_upload = h.up_stats.valid && A.ptr == h.in_ptr.p && A.idx == h.in_idx.p && A.val == h.in_val.p &&
+                           h.up_stats.m == (uint64_t)m && h.up_stats.n == (uint64_t)n && h.up_stats.nnz == (uint64_t)nnz &&
+                           h.up_stats.dtype == kDtype && n > 0 && !h.comm.active();   // (ranks must not differ in their collectives)
+  auto column_statistics = [&](bool uploaded) {
     Scope sc(h, C_STATS);
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
-    if constexpr (sizeof(T) == 4) {
-      // packed tile-major rows: the statistics pass also leaves the A^T builder's per-row tile index behind
-      if (at_packed) {
-        k::at_stats_index(At.ptr, at_packed, n, m, tiled_ldp, h.tb_at, d_stats, d_stats + n, s);
-        at_seg_ready = true;
+    if (uploaded) {
+      SAPCA_HIP(hipStreamWaitEvent(s, h.up_stats_done, 0));
+      SAPCA_HIP(hipMemcpyAsync(d_stats, h.up_stats.out.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    } else {
+      if constexpr (sizeof(T) == 4) {
+        // packed tile-major rows: the statistics pass also leaves the A^T builder's per-row tile index behind
+        if (at_packed) {
+          k::at_stats_index(At.ptr, at_packed, n, m, tiled_ldp, h.tb_at, d_stats, d_stats + n, s);
+          at_seg_ready = true;
+        }
       }
+      if (!at_seg_ready) k::row_sums(At, d_stats, d_stats + n, s);
+      k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
     }
-    if (!at_seg_ready) k::row_sums(At, d_stats, d_stats + n, s);
-    k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
     const double m_local = (double)m;
     SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &m_local, sizeof(double), hipMemcpyHostToDevice, s));
     if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s); }
     SAPCA_HIP(hipMemcpyAsync(sums.data(), d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipMemcpyAsync(&sums[(size_t)2 * n], d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));
+  };
+  column_statistics(from_upload);
+  // the accumulators refuse inf/nan (the flag is final once the stream has passed up_stats_done): the row sums take over
+  if (from_upload && *static_cast<const int*>(h.up_stats.flag.p) != 0) {
+    h.up_stats.valid = false;
+    column_statistics(false);
   }
   h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
   const double mg = (double)h.m_global;

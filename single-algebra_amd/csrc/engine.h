@@ -56,6 +56,16 @@ struct sapca_handle_s {
   sapca::DevBuf in_ptr, in_idx, in_val, up64, up64i, out_tmp;    // host-entry uploads
   sapca::PinnedBuf up_stage[2];                                   // page-locked ring of the chunked index upload
   hipEvent_t up_done[2] = {nullptr, nullptr};
+  // column statistics accumulated chunk by chunk while the upload is in flight (upstats.hip); valid for exactly the
+  // matrix in (in_ptr, in_idx, in_val) until one of the library's entry points rewrites its values
+  struct UpStats {
+    sapca::DevBuf work, out;            // long accumulators; sum | sumsq | count (f64, n each)
+    sapca::PinnedBuf flag;              // 1: a value was inf/nan and `out` is void (readable once up_stats_done has passed)
+    uint64_t m = 0, n = 0, nnz = 0;
+    int dtype = -1;
+    bool valid = false;
+  } up_stats;
+  hipEvent_t up_stats_done = nullptr;
   sapca::DevBuf at_ptr, at_idx, at_val;                          // A^T
   sapca::DevBuf ca_ptr, ca_idx, ca_val, cat_ptr, cat_idx, cat_val;  // mask-compacted A, A^T
   sapca::DevBuf shifted_val;                                     // a_ij - mu_j (quirk Q3 operand)

@@ -31,6 +31,18 @@ void select_rows(const CsrView<T>& At, const int32_t* rows, int64_t n_sel, int64
 // vals_out[e] = vals[e] - mu_full[cols_to_use[idx[e]]]   (quirk Q3 operand)
 template <typename T>
 void subtract_column_mean(const CsrView<T>& A, const T* mu_by_col, T* vals_out, hipStream_t s);
+// Exact, order-independent column statistics of a CSR whose entries land chunk by chunk (upstats.hip).  `work` holds the
+// long accumulators.  scan_values (once all values are on the device) fixes the limb window kept in LDS; add takes the
+// entries [e_lo, e_hi) of rows [r_lo, r_hi); finish writes out[0..n) = sum, out[n..2n) = sum of squares, out[2n..3n) =
+// stored-entry count, each the correctly rounded exact value, and copies the "a value was inf/nan" flag to the host
+// asynchronously.
+template <typename T> size_t exact_colstats_bytes(int64_t n);
+template <typename T> void exact_colstats_reset(void* work, int64_t n, hipStream_t s);
+template <typename T> void exact_colstats_scan_values(const T* val, int64_t count, int64_t n, void* work, hipStream_t s);
+template <typename T>
+void exact_colstats_add(const int64_t* ptr, const int32_t* idx, const T* val, int64_t r_lo, int64_t r_hi, int64_t e_lo, int64_t e_hi,
+                        int64_t n, void* work, hipStream_t s);
+template <typename T> void exact_colstats_finish(void* work, int64_t n, double* out, int* nonfinite_host, hipStream_t s);
 // out[r] = ptr[r+1] - ptr[r] as f64 (column counts when applied to A^T's row offsets)
 void row_lengths_f64(const int64_t* ptr, int64_t rows, double* out, hipStream_t s);
 // out[j] = number of stored entries with column j (integer atomics; transform of a matrix that

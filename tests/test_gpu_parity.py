@@ -52,6 +52,72 @@ def test_g1_colstats(golden, session, dtype, tol):
     assert cnt.tolist() == g["cnt"].tolist()
 
 
+def _exact_column_sums(idx, val, n):
+    """correctly rounded exact column sums and sums of squares (math.fsum; squares as exact fractions)"""
+    from fractions import Fraction
+    import math
+    cols = [[] for _ in range(n)]
+    for j, v in zip(idx.tolist(), val.tolist()):
+        cols[j].append(v)
+    s = np.array([math.fsum(c) for c in cols])
+    sq = np.array([float(sum((Fraction(v) * Fraction(v) for v in c), Fraction(0))) for c in cols])
+    return s, sq
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_statistics_gathered_behind_the_upload_are_the_exact_sums(session, dtype):
+    """the column statistics of a host matrix are accumulated chunk by chunk behind the DMA into long integer
+    accumulators -- order-independent, rounded once.  Values over 80 binades with heavy cancellation: the result equals the
+    correctly rounded exact sum bit for bit; the row sums of A^T (the route of device-resident input) agree to rounding."""
+    rng = np.random.default_rng(11)
+    m, n = 4000, 300
+    A = sp.random(m, n, density=0.05, format="csr", random_state=5, dtype=np.float64)
+    A.sort_indices()
+    v = rng.standard_normal(A.nnz) * np.exp2(rng.integers(-40, 41, A.nnz))
+    kk = (A.nnz - 1) // 7
+    v[0:7 * kk:7] = -v[1:7 * kk + 1:7]                    # cancellation between entries that may share a column
+    v[5] = 0.0                                            # a stored zero counts as an entry
+    if dtype == np.float32:
+        v[11] = np.float32(1e-42)                         # a subnormal
+    val = v.astype(dtype)
+    ptr, idx = A.indptr.astype(np.int64), A.indices.astype(np.int64)
+    s, sq, cnt = session.colstats(ptr, idx, val, m, n)
+    want_s, want_sq = _exact_column_sums(idx, val.astype(np.float64), n)
+    assert np.array_equal(s, want_s.astype(dtype))        # (f32: the exact sum rounded to f64, then to f32 on the way out)
+    assert np.array_equal(sq, want_sq.astype(dtype))
+    assert np.array_equal(cnt.astype(np.int64), np.bincount(idx, minlength=n))
+    # the other route, reached through a matrix the accumulators refuse: one inf switches them off for that upload
+    val2 = val.copy()
+    val2[3] = np.inf
+    s2, sq2, cnt2 = session.colstats(ptr, idx, val2, m, n)
+    keep = np.ones(n, bool)
+    keep[idx[3]] = False
+    np.testing.assert_allclose(s2[keep], want_s[keep], rtol=1e-12 if dtype == np.float64 else 1e-6, atol=1e-30)
+    assert np.isinf(s2[idx[3]]) and np.array_equal(cnt2, cnt)
+
+
+def test_host_fits_are_bitwise_reproducible_and_match_resident_fits(monkeypatch):
+    """the statistics gathered behind the upload do not depend on the order the chunks' atomics land in: two host fits are
+    bit-identical; the same matrix fitted from device-resident arrays (row sums of A^T) gives the same model to rounding"""
+    m, n, k, p, q = 20000, 1500, 10, 6, 2
+    dev = synth.gapped_csr(m, n, 0.04, k, seed=9, dtype=torch.float32, device="cuda")
+    ptr, idx, val = csr_np(dev)
+    om = synth.gaussian_panel(n, k + p, 3).numpy()
+    runs = []
+    for _ in range(2):
+        pca = _builder(k, p, q).build().set_omega(om)
+        t = pca.fit_transform(mat(ptr, idx, val, m, n))
+        runs.append((pca.mean_(np.float64), pca.explained_variance_ratio(np.float64), pca.components_(np.float64), t))
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)
+    res = _builder(k, p, q).build().set_omega(om)
+    t_res = res.fit_transform(sapca.DeviceCsr(*dev, (m, n))).cpu().numpy()
+    np.testing.assert_allclose(runs[0][0], res.mean_(np.float64), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(runs[0][1], res.explained_variance_ratio(np.float64), rtol=1e-5)
+    assert O.subspace_angle(runs[0][2], res.components_(np.float64)) < 1e-4
+    np.testing.assert_allclose(runs[0][3], t_res, atol=2e-4 * np.abs(t_res).max())
+
+
 def test_colstats_large_matches_oracle(session):
     ptr, idx, val = csr_np(synth.flat_csr(3000, 1000, 0.1, seed=3, dtype=torch.float64))
     s, sq, cnt = session.colstats(ptr, idx, val, 3000, 1000)
