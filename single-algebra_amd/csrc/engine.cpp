@@ -12,6 +12,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <exception>
+#include <thread>
 
 #include "lanczos.h"
 #include "small_svd.h"
@@ -120,6 +122,32 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   const bool from_at = getenv("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
   const bool at_tile_major = sizeof(T) == 4 && tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
 
+  // mask index maps (sparse_masked/mod.rs:264-271 and the HashMap of :462-466)
+  h.cols_to_use.clear();
+  h.orig_to_masked.clear();
+  h.has_mask_maps = masked;
+  std::vector<int32_t> o2m32, sel;   // (alive until the copies below have been synchronised)
+  int32_t *d_o2m = nullptr, *d_sel = nullptr;
+  if (masked) {
+    h.orig_to_masked.assign((size_t)n, -1);
+    for (int64_t j = 0; j < n; ++j)
+      if (h.mask[(size_t)j]) {
+        h.orig_to_masked[(size_t)j] = (int64_t)h.cols_to_use.size();
+        h.cols_to_use.push_back((uint64_t)j);
+      }
+  }
+  const int64_t n_used = masked ? (int64_t)h.cols_to_use.size() : n;
+  if (masked) {
+    o2m32.resize((size_t)n);
+    sel.resize((size_t)std::max<int64_t>(n_used, 1));
+    for (int64_t j = 0; j < n; ++j) o2m32[(size_t)j] = (int32_t)h.orig_to_masked[(size_t)j];
+    for (int64_t j = 0; j < n_used; ++j) sel[(size_t)j] = (int32_t)h.cols_to_use[(size_t)j];
+    d_o2m = h.o2m_dev.as<int32_t>((size_t)std::max<int64_t>(n, 1));
+    d_sel = h.sel_rows_dev.as<int32_t>((size_t)std::max<int64_t>(n_used, 1));
+    SAPCA_HIP(hipMemcpyAsync(d_o2m, o2m32.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    SAPCA_HIP(hipMemcpyAsync(d_sel, sel.data(), (size_t)n_used * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  }
+
   CsrView<T> At;
   const uint64_t* at_packed = nullptr;
   bool at_seg_ready = false;
@@ -139,6 +167,45 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   // A's format does not depend on the transposition: build it on a side stream while the sort runs on the
   // main one (both are memory-latency bound and overlap well); the main stream joins before the first sweep.
   bool a_built_aside = false, ok_a_aside = false;
+  // Masked fits: A's side is the column compaction (MaskedCSRMatrix::new, sparse_masked/mod.rs:313) and then the format
+  // of the compacted matrix.  Both synchronise with the host (entry counts come back), so a helper thread drives them on
+  // the side stream while this one keeps the main stream fed (statistics, row selection of A^T, A^T's format).
+  std::thread aside;
+  std::exception_ptr aside_err;
+  int64_t nnz_used = 0;
+  struct Joiner {   // (an exception on the main path must not leave the helper running into freed state)
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{aside};
+  const bool masked_aside = masked && n_used > 0 && getenv("SAPCA_PREPARE_SERIAL") == nullptr;
+  if (masked_aside) {
+    if (!h.stream2) {
+      SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
+      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
+      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
+    }
+    SAPCA_HIP(hipEventRecord(h.ev_fork, s));   // A and the index maps are on the device
+    h.tiled_a = TiledOp();
+    a_built_aside = true;
+    aside = std::thread([&, n_used, tiled_ldp] {
+      try {
+        SAPCA_HIP(hipSetDevice(h.device));
+        SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
+        int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
+        int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+        T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+        k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.tb_a.tmp, h.stream2);
+        h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
+        if (tiled_ldp != 0) {
+          if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+          else ok_a_aside = k::build_tiled(view(h.a_used), tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+        }
+        SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));
+      } catch (...) {
+        aside_err = std::current_exception();
+      }
+    });
+  }
   {
     if (tiled_ldp != 0 && !masked && getenv("SAPCA_PREPARE_SERIAL") == nullptr) {
       if (!h.stream2) {
@@ -195,20 +262,6 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
   const double mg = (double)h.m_global;
 
-  // mask index maps (sparse_masked/mod.rs:264-271 and the HashMap of :462-466)
-  h.cols_to_use.clear();
-  h.orig_to_masked.clear();
-  h.has_mask_maps = masked;
-  if (masked) {
-    h.orig_to_masked.assign((size_t)n, -1);
-    for (int64_t j = 0; j < n; ++j)
-      if (h.mask[(size_t)j]) {
-        h.orig_to_masked[(size_t)j] = (int64_t)h.cols_to_use.size();
-        h.cols_to_use.push_back((uint64_t)j);
-      }
-  }
-  const int64_t n_used = masked ? (int64_t)h.cols_to_use.size() : n;
-
   // R3: mean and total variance (sparse/mod.rs:106-131; masked :273-311, over cols_to_use only)
   h.prep_mean.assign((size_t)n, 0.0);
   h.prep_total_var = 0;
@@ -223,31 +276,31 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   }
 
   // operator seen by the SVD engines: MaskedCSRMatrix::new (sparse_masked/mod.rs:313)
+  int64_t nnz_used_t = 0;
   if (masked) {
     Scope sc(h, C_PREPARE);
-    std::vector<int32_t> o2m32((size_t)n), sel((size_t)std::max<int64_t>(n_used, 1));
-    for (int64_t j = 0; j < n; ++j) o2m32[(size_t)j] = (int32_t)h.orig_to_masked[(size_t)j];
-    for (int64_t j = 0; j < n_used; ++j) sel[(size_t)j] = (int32_t)h.cols_to_use[(size_t)j];
-    int32_t* d_o2m = h.o2m_dev.as<int32_t>((size_t)std::max<int64_t>(n, 1));
-    int32_t* d_sel = h.sel_rows_dev.as<int32_t>((size_t)std::max<int64_t>(n_used, 1));
-    SAPCA_HIP(hipMemcpyAsync(d_o2m, o2m32.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    SAPCA_HIP(hipMemcpyAsync(d_sel, sel.data(), (size_t)n_used * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
-    int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
-    T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    int64_t nnz_used = 0, nnz_used_t = 0;
-    k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s);
+    if (!masked_aside) {
+      int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
+      int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+      T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+      k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s);
+      h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
+    }
     int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
     int32_t* cat_idx = h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* cat_val = h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
     k::select_rows(At, d_sel, n_used, cat_ptr, cat_idx, cat_val, &nnz_used_t, h.scratch, s);
-    SAPCA_CHECK(nnz_used == nnz_used_t, SAPCA_ERR_HIP, "internal: mask compaction of A and A^T disagree");
-    h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
-    h.at_used = {n_used, m, nnz_used, cat_ptr, cat_idx, cat_val};
+    h.at_used = {n_used, m, nnz_used_t, cat_ptr, cat_idx, cat_val};
   } else {
     h.a_used = {m, n, nnz, A.ptr, A.idx, A.val};
     h.at_used = {n, m, nnz, At.ptr, At.idx, At.val};
   }
+  // (the helper thread is joined below, after A^T's format has been enqueued on the main stream)
+  auto join_aside = [&] {
+    if (aside.joinable()) aside.join();
+    if (aside_err) std::rethrow_exception(aside_err);
+    if (masked) SAPCA_CHECK(nnz_used == nnz_used_t, SAPCA_ERR_HIP, "internal: mask compaction of A and A^T disagree");
+  };
 
   // tile-major companions for the LDS-staged sweep
   if (!a_built_aside) h.tiled_a = TiledOp();
@@ -255,15 +308,18 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   if constexpr (sizeof(T) == 4) {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
-      const bool ok_a = a_built_aside ? ok_a_aside : k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
-      bool ok_at = ok_a && ((!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
-                            k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed, true,
-                                           at_seg_ready));
+      if (!a_built_aside) ok_a_aside = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
+      if (!from_at) join_aside();   // (this route reads the compacted A)
+      bool ok_at = (!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
+                   k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed, true, at_seg_ready);
       if (at_packed && !ok_at) {   // someone needs the transposed CSR after all
         k::unpack_transposed(at_packed, nnz, const_cast<int32_t*>(At.idx), reinterpret_cast<float*>(const_cast<T*>(At.val)), s);
         at_packed = nullptr;
-        ok_at = ok_a && k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major);
+        ok_at = k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major);
       }
+      join_aside();
+      const bool ok_a = ok_a_aside;
+      ok_at = ok_at && ok_a;
       if (h.opt.verbose)
         fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
                 ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
@@ -273,8 +329,11 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   } else {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
-      const bool ok_a = a_built_aside ? ok_a_aside : k::build_tiled(view(h.a_used), tiled_ldp, h.tiled_a, h.tb_a, s);
-      const bool ok_at = ok_a && k::build_tiled(view(h.at_used), tiled_ldp, h.tiled_at, h.tb_at, s);
+      if (!a_built_aside) ok_a_aside = k::build_tiled(view(h.a_used), tiled_ldp, h.tiled_a, h.tb_a, s);
+      bool ok_at = k::build_tiled(view(h.at_used), tiled_ldp, h.tiled_at, h.tb_at, s);
+      join_aside();
+      const bool ok_a = ok_a_aside;
+      ok_at = ok_at && ok_a;
       if (h.opt.verbose)
         fprintf(stderr, "sapca: tile-major formats (f64): A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
                 ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
@@ -283,6 +342,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     }
   }
 
+  join_aside();   // (fits without tile-major formats)
   if (a_built_aside) SAPCA_HIP(hipStreamWaitEvent(s, h.ev_join, 0));
 
   h.prep_key.ptr = A.ptr; h.prep_key.idx = A.idx; h.prep_key.val = A.val;
