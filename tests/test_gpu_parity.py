@@ -644,11 +644,13 @@ def test_g3_spmm_tiled(golden, session_tiled, l):
 
 @pytest.mark.parametrize("shape,dens,l", [((5000, 3000), 0.02, 60), ((700, 300), 0.05, 110), ((3000, 40000), 0.004, 60),
                                           ((70000, 900), 0.01, 20), ((1000, 1000), 0.0, 16), ((20000, 640), 0.9, 60),
-                                          ((3000, 700), 0.5, 64)])
+                                          ((3000, 700), 0.5, 64), ((3, 1), 1.0, 4), ((64, 2), 0.7, 8), ((1025, 321), 0.2, 60),
+                                          ((2, 700), 0.5, 30), ((4097, 319), 0.05, 64)])
 def test_spmm_tiled_matches_row_kernel(session, session_tiled, shape, dens, l):
     """ragged shapes: several row blocks, split tile ranges, wide panels, an empty matrix, nearly dense operators (a
     wave's stream in one tile far longer than the 32 chunks one descriptor register covers, with 1024- and 512-row
-    blocks); the two sweep kernels must agree to f32 rounding on both A and A^T"""
+    blocks), panels of one to a few rows (every LDS-DMA piece clamps its source rows) and of one row short of / past a
+    tile; the two sweep kernels must agree to f32 rounding on both A and A^T"""
     m, n = shape
     ptr, idx, val = csr_np(synth.flat_csr(m, n, dens, seed=8, dtype=torch.float32))
     X = synth.gaussian_panel(n, l, 3).numpy().astype(np.float32)
