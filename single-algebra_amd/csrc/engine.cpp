@@ -696,13 +696,24 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     } else if (ref_sem && masked) {
       // Q3 (sparse_masked/mod.rs:488-529): mean subtracted at stored, kept entries only
       k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
-      CsrView<T> As = Au;
-      if (center) {
-        T* sv = h.shifted_val.as<T>((size_t)std::max<int64_t>(Au.nnz, 1));
-        k::subtract_column_mean(Au, mu, sv, s);
-        As.val = sv;
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        // the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (spmm_dq.hip)
+        if (center && top && h.opt.spmm_variant != 1 && getenv("SAPCA_Q3_ROWKERNEL") == nullptr) {
+          float* W2 = h.scratch2.as<float>((size_t)n_used * ldk);
+          float* tmp = h.panel_y.as<float>((size_t)m * std::max(k, 1));
+          done = k::q3_projection_dq(Au, *top, W, ldk, mu, W2, tmp, d_out, k, s);
+        }
       }
-      k::spmm(As, center ? nullptr : top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
+      if (!done) {
+        CsrView<T> As = Au;
+        if (center) {
+          T* sv = h.shifted_val.as<T>((size_t)std::max<int64_t>(Au.nnz, 1));
+          k::subtract_column_mean(Au, mu, sv, s);
+          As.val = sv;
+        }
+        k::spmm(As, center ? nullptr : top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
+      }
     } else {
       // opt-in: the mathematically centred projection (A - 1 mu^T) V^T
       k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);

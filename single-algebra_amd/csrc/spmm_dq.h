@@ -10,7 +10,13 @@ namespace k {
 // the staged-entry quad sweep.
 bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s);
 bool dq_usable(const TiledOp& op, int ldx);
-void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s);
+// flags: 8 = pattern mode (every stored non-zero value reads as 1)
+void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s, int flags = 0);
+// out (m x k, leading dimension k) = sum over the stored entries of row i of (a_ij - mu_j) W[j][:k]   (quirk Q3) as two sweeps of
+// the operator's format plus a pass over the values for stored zeros.  W2 (cols x ldw) and tmp (m x k) are scratch.  Returns false
+// when the operator cannot take the DPP-fed sweep (nothing is launched).
+bool q3_projection_dq(const CsrView<float>& A, const TiledOp& op, const float* W, int ldw, const float* mu, float* W2, float* tmp,
+                      float* out, int k, hipStream_t s);
 
 }  // namespace k
 }  // namespace sapca

@@ -22,6 +22,8 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include <algorithm>
+
 #include "spmm_dq.h"
 #include "spmm_dq_gen.h"
 
@@ -195,18 +197,74 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
 bool dq_usable(const TiledOp& op, int ldx) { return op.dq && (ldx == 64 || ldx == 128); }
 
 template <int RG>
-static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s) {
+static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int flags,
+                        hipStream_t s) {
   static LdsAttrState attr;
-  static const int mode = getenv("SAPCA_DQ_MODE") ? atoi(getenv("SAPCA_DQ_MODE")) : 0;   // 1: tile loop without compute (timing only)
+  static const int mode = getenv("SAPCA_DQ_MODE") ? atoi(getenv("SAPCA_DQ_MODE")) & 7 : 0;   // 1: tile loop without compute (timing only)
   ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_dq_kernel<RG>), DQ_LDS, attr);
   hipLaunchKernelGGL(spmm_dq_kernel<RG>, dim3((unsigned)(op.nrb * op.nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm,
                      op.nct, reinterpret_cast<const uint64_t*>(op.ent), op.dq_desc, op.dq_info, op.cols, X, ldx, op.nsplit,
-                     op.tiles_per_split, out, op.rows, ldo, ncols, cvec, mode);
+                     op.tiles_per_split, out, op.rows, ldo, ncols, cvec, mode | flags);
 }
 
-void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s) {
-  if (op.block_rows == 1024) launch_dq_t<16>(op, X, ldx, out, ldo, ncols, cvec, s);
-  else launch_dq_t<8>(op, X, ldx, out, ldo, ncols, cvec, s);
+void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s, int flags) {
+  if (op.block_rows == 1024) launch_dq_t<16>(op, X, ldx, out, ldo, ncols, cvec, flags, s);
+  else launch_dq_t<8>(op, X, ldx, out, ldo, ncols, cvec, flags, s);
+}
+
+// ---- MaskedSparsePCA::transform (quirk Q3, /root/reference/src/dimred/pca/sparse_masked/mod.rs:488-529) through the sweep ---------
+// t_ik = sum over the stored, kept entries of row i of (a_ij - mu_j) W_jk  =  (A W)_ik - (P diag(mu) W)_ik, P the pattern of the
+// stored entries.  The second product is the same sweep with every stored non-zero value read as 1 (mode bit 3); stored zeros look
+// like the format's padding there, so a pass over the values finds them (rare) and adds their -mu_j W_j by hand.
+namespace {
+__global__ void scale_rows_kernel(const float* __restrict__ W, int64_t n, int ld, const float* __restrict__ mu, float* __restrict__ out) {
+  const int64_t total = n * ld, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) out[i] = W[i] * mu[i / ld];
+}
+
+__global__ void subtract_kernel(float* __restrict__ out, const float* __restrict__ sub, int64_t count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] -= sub[i];
+}
+
+// one wave per row: out[i][:] -= mu_j W[j][:] for every stored entry of the row whose value is zero
+__global__ void __launch_bounds__(256)
+stored_zero_fix_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val, int64_t rows,
+                       const float* __restrict__ mu, const float* __restrict__ W, int ldw, int k, float* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t e0 = ptr[r]; e0 < e1; e0 += WAVE) {
+      const int64_t e = e0 + lane;
+      unsigned long long zeros = __ballot(e < e1 && val[e] == 0.f);
+      while (zeros) {
+        const int b = __builtin_ctzll(zeros);
+        zeros &= zeros - 1;
+        const int64_t j = idx[e0 + b];
+        const float m = mu[j];
+        for (int c = lane; c < k; c += WAVE) out[r * ldo + c] -= m * W[j * ldw + c];
+      }
+    }
+  }
+}
+}  // namespace
+
+bool q3_projection_dq(const CsrView<float>& A, const TiledOp& op, const float* W, int ldw, const float* mu, float* W2, float* tmp,
+                      float* out, int k, hipStream_t s) {
+  if (!op.valid || op.nsplit != 1 || !dq_usable(op, ldw) || op.rows != A.rows || op.cols != A.cols || k > ldw) return false;
+  const int64_t n = A.cols, m = A.rows;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)std::min<int64_t>((n * ldw + 255) / 256, 4096)), dim3(256), 0, s, W, n, ldw, mu, W2);
+  for (int c0 = 0; c0 < k; c0 += op.ldp) {   // 64 columns of the panel per pass
+    const int nc = std::min(k - c0, op.ldp);
+    launch_dq(op, W + c0, ldw, out + c0, k, nc, nullptr, s, 0);
+    launch_dq(op, W2 + c0, ldw, tmp + c0, k, nc, nullptr, s, 8);
+  }
+  hipLaunchKernelGGL(subtract_kernel, dim3((unsigned)std::min<int64_t>((m * k + 255) / 256, 4096)), dim3(256), 0, s, out, tmp, m * (int64_t)k);
+  hipLaunchKernelGGL(stored_zero_fix_kernel, dim3((unsigned)std::min<int64_t>((m + 3) / 4, 8192)), dim3(256), 0, s, A.ptr, A.idx, A.val, m,
+                     mu, W, ldw, k, out, k);
+  SAPCA_HIP(hipGetLastError());
+  return true;
 }
 
 }  // namespace k

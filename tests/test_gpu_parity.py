@@ -362,6 +362,40 @@ def test_masked_randomized_fit_vs_oracle(dtype, ang):
     assert np.array_equal(cols, want.cols_to_use) and np.array_equal(o2m, want.orig_to_masked)
 
 
+def test_masked_projection_through_the_sweep_with_stored_zeros(monkeypatch):
+    """quirk Q3 through the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (the second reads every stored
+    non-zero value as 1) plus the stored zeros by hand -- here a few hundred stored +0.0 / -0.0 entries, which the format
+    cannot tell from its padding.  Against the oracle's entry loop, and against the row kernel on shifted values."""
+    m, n, k, p, q = 9000, 1400, 12, 6, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.05, k, seed=33, dtype=torch.float32))
+    rng = np.random.default_rng(4)
+    z = rng.choice(len(val), 400, replace=False)
+    val = val.copy()
+    val[z[:200]] = 0.0
+    val[z[200:]] = -0.0
+    mask = synth.bernoulli_mask(n, 0.7, 3).numpy()
+    n_used = int(mask.sum())
+    om = synth.gaussian_panel(n_used, k + p, 5).numpy()
+    A = sp.csr_matrix((val, idx, ptr), shape=(m, n))          # (scipy keeps the stored zeros)
+    assert A.nnz == len(val)
+    out = {}
+    for route in ("sweep", "rowkernel"):
+        if route == "rowkernel":
+            monkeypatch.setenv("SAPCA_Q3_ROWKERNEL", "1")
+        est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).spmm_variant(2).collect_timings(True)
+               .svd_method(SVDMethod.Random(p, q, PIN.QR)).build().set_omega(om))
+        out[route] = est.fit_transform(A)
+        comps, mean = est.components_(np.float64), est.mean_(np.float64)
+    want = O.transform_masked_fast(ptr, idx, val.astype(np.float64), m, n, comps, mean, True, mask)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(out["sweep"], want, atol=2e-5 * scale)
+    np.testing.assert_allclose(out["rowkernel"], want, atol=2e-5 * scale)
+    # the stored zeros matter at this tolerance: dropping them moves their rows by |mu_j V_kj|
+    dropped = O.transform_masked_fast(*(lambda B: (B.indptr.astype(np.int64), B.indices.astype(np.int64), B.data.astype(np.float64)))(
+        (lambda B: (B.eliminate_zeros(), B)[1])(A.copy())), m, n, comps, mean, True, mask)
+    assert np.abs(dropped - want).max() > 2e-4 * scale          # ten times the tolerance above
+
+
 # ------------------------------------------------------------------ errors (reference messages)
 def test_error_behaviour():
     ptr, idx, val = csr_np(synth.flat_csr(50, 20, 0.3, dtype=torch.float64))

@@ -209,6 +209,10 @@ def chunk_body(buf, L, O):
     O += [f"v_mov_b32 v{VDESC}, v{VDESC2}", f"s_branch {lbl}_ready"]
     # a descriptor register covers 32 chunks: longer streams (dense tiles) reload it, everything waited for
     L += [f"s_cmp_ge_u32 s{S_DL}, 64", f"s_cbranch_scc1 {lbl}_dreload", f"{lbl}_dok:"]
+    # pattern mode (mode bit 3; MaskedSparsePCA's projection, quirk Q3): every stored non-zero value counts as 1, zeros
+    # (padding, and stored zeros, which the caller handles) as 0 -- rewritten once in the freshly loaded entry registers
+    L += ["s_bitcmp1_b32 %[mode], 3", f"s_cbranch_scc1 {lbl}_pat", f"{lbl}_patdone:"]
+    O += [f"{lbl}_pat:", f"v_cmp_neq_f32 vcc, 0, v{e[1]}", f"v_cndmask_b32_e64 v{e[1]}, 0, 1.0, vcc", f"s_branch {lbl}_patdone"]
     O += [f"{lbl}_dreload:", f"s_add_u32 s{S_DP}, s{S_DP}, 0x100", f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0",
           f"global_load_dword v{VDESC}, %[l4], s[{S_DP}:{S_DP + 1}]", "s_waitcnt vmcnt(0)", f"s_mov_b32 s{S_N1}, 0", f"s_mov_b32 s{S_N2}, 0",
           f"s_mov_b32 s{S_DL}, 0", f"s_branch {lbl}_dok"]
