@@ -134,7 +134,11 @@ sapca_status sapca_set_mask(sapca_handle h, const uint8_t* mask, size_t len);
 sapca_status sapca_set_omega_f32(sapca_handle h, const float* omega, size_t rows, size_t cols);
 sapca_status sapca_set_omega_f64(sapca_handle h, const double* omega, size_t rows, size_t cols);
 
-/* SparsePCA::fit / MaskedSparsePCA::fit          sparse/mod.rs:102-242; masked :255-419        */
+/* SparsePCA::fit / MaskedSparsePCA::fit          sparse/mod.rs:102-242; masked :255-419
+ * Host matrices: the column statistics of the fit (sum_col, sum_col_squared, csr.rs:259-312 and
+ * 558-608, and the per-column counts) are gathered behind the upload's DMA as exact sums rounded
+ * once -- independent of summation order, hence bit-reproducible; inf/nan values switch to the
+ * row sums of the transposed matrix, which device-resident inputs always use.                  */
 sapca_status sapca_fit_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
                                const uint64_t* row_offsets, const uint64_t* col_indices, const float* values);
 sapca_status sapca_fit_csr_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
@@ -238,7 +242,8 @@ sapca_status sapca_generate_omega_f64(sapca_handle h, uint64_t rows, uint64_t l,
  * sapca_upload_csr_* copies a host CsrMatrix (usize indices) into buffers owned by the handle and
  * returns the device arrays (valid until the next host-matrix call on this handle or its
  * destruction); the *_device_* entry points below and sapca_fit*_csr_device_* then work on them
- * without touching PCIe again.                                                                  */
+ * without touching PCIe again.  The column statistics gathered during the upload serve a fit of
+ * the arrays as uploaded; normalize / log1p on them drop those statistics.                      */
 sapca_status sapca_upload_csr_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
                                   const uint64_t* row_offsets, const uint64_t* col_indices, const float* values,
                                   const int64_t** d_row_offsets, const int32_t** d_col_indices, float** d_values);
