@@ -396,6 +396,56 @@ def test_masked_projection_through_the_sweep_with_stored_zeros(monkeypatch):
     assert np.abs(dropped - want).max() > 2e-4 * scale          # ten times the tolerance above
 
 
+def _random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(1, 13))
+    m = int(rng.integers(40, 2500))
+    n = int(rng.integers(max(24, 2 * k + 8), 1300))
+    return dict(
+        m=m, n=n, k=k, dens=float(rng.uniform(0.02, 0.3)), p=int(rng.integers(1, 9)), q=int(rng.integers(0, 4)),
+        norm=[PIN.QR, PIN.LU, PIN.NONE][int(rng.integers(0, 3))], center=bool(rng.integers(0, 2)), masked=bool(rng.integers(0, 2)),
+        dtype=[np.float32, np.float64][int(rng.integers(0, 2))], variant=[0, 1, 2][int(rng.integers(0, 3))])
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations_against_the_oracle(seed):
+    """random shapes, densities, ranks, oversampling, power iterations, normalisers, centring on / off, with and without a
+    mask, f32 / f64, each sweep kernel: fit and transform against the oracle run on the same matrix with the same Omega"""
+    c = _random_case(seed)
+    m, n, k, p, q = c["m"], c["n"], c["k"], c["p"], c["q"]
+    if c["norm"] == PIN.NONE:
+        q = min(q, 2)                      # un-normalised power iterations square the conditioning each round
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, c["dens"], k, seed=seed, dtype=torch.float64))
+    mask = synth.bernoulli_mask(n, 0.7, seed).numpy() if c["masked"] else None
+    n_used = int(mask.sum()) if c["masked"] else n
+    l = min(k + p, m, n_used)
+    if k > l:
+        pytest.skip("mask left fewer columns than components")
+    om = synth.gaussian_panel(n_used, k + p, seed + 7).numpy()
+    norm_name = {PIN.QR: "QR", PIN.LU: "LU", PIN.NONE: "NONE"}[c["norm"]]
+    want = O.fit(ptr, idx, val, m, n, n_components=k, n_oversamples=p, n_power_iterations=q, normalizer=norm_name,
+                 center=c["center"], omega=om, mask=mask)
+    if c["masked"]:
+        b = sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask)
+    else:
+        b = sapca.SparsePCABuilder.new().n_components(k)
+    est = b.center(c["center"]).spmm_variant(c["variant"]).svd_method(SVDMethod.Random(p, q, c["norm"])).build().set_omega(om)
+    A = mat(ptr, idx, val.astype(c["dtype"]), m, n)
+    t = est.fit_transform(A)
+    f32 = c["dtype"] == np.float32
+    s_got, s_want = est.singular_values_(np.float64), want.singular_values
+    np.testing.assert_allclose(s_got, s_want, rtol=2e-3 if f32 else 1e-7, err_msg=str(c))
+    np.testing.assert_allclose(est.mean_(np.float64), want.mean, atol=1e-5 if f32 else 1e-12, err_msg=str(c))
+    # (the generator plants a rank-k signal clear of the noise floor: the top-k subspace is well defined)
+    assert O.subspace_angle(est.components_(np.float64), want.components) < (2e-2 if f32 else 1e-5), str(c)
+    comps, mean = est.components_(np.float64), est.mean_(np.float64)
+    if c["masked"]:
+        tw = O.transform_masked_fast(ptr, idx, val, m, n, comps, mean, c["center"], mask)
+    else:
+        tw = O.transform_sparse(ptr, idx, val, m, n, comps, mean, c["center"])
+    np.testing.assert_allclose(t, tw, atol=(5e-4 if f32 else 1e-9) * max(1.0, float(np.abs(tw).max())), err_msg=str(c))
+
+
 # ------------------------------------------------------------------ errors (reference messages)
 def test_error_behaviour():
     ptr, idx, val = csr_np(synth.flat_csr(50, 20, 0.3, dtype=torch.float64))
@@ -642,6 +692,38 @@ def test_lanczos_wide_matrix_uses_the_small_side():
     _, s, vt = np.linalg.svd(A.toarray(), full_matrices=False)
     np.testing.assert_allclose(pca.singular_values_(), s[:k], rtol=1e-5)
     assert O.subspace_angle(pca.components_(), vt[:k]) < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_lanczos_configurations_against_the_exact_svd(seed):
+    """svd_las2 on random shapes (tall and wide), with and without a mask, f32 / f64: singular values and the top-k right
+    subspace of the raw operator (quirk Q1: Lanczos fits are uncentred) against numpy's SVD of the dense matrix"""
+    rng = np.random.default_rng(500 + seed)
+    k = int(rng.integers(1, 9))
+    m, n = int(rng.integers(60, 1800)), int(rng.integers(40, 1500))
+    dens = float(rng.uniform(0.03, 0.25))
+    masked, f32 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, dens, k, seed=seed, centred=False, dtype=torch.float64))
+    A = mat(ptr, idx, val.astype(np.float32 if f32 else np.float64), m, n)
+    mask = synth.bernoulli_mask(n, 0.7, seed).numpy() if masked else np.ones(n, bool)
+    if masked:
+        est = sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).svd_method(SVDMethod.Lanczos()).build()
+    else:
+        est = sapca.SparsePCABuilder.new().n_components(k).build()
+    D = A.toarray().astype(np.float64)[:, mask]
+    if min(D.shape) < k + 2:
+        pytest.skip("mask left too few columns")
+    est.fit(A)
+    _, s, vt = np.linalg.svd(D, full_matrices=False)
+    np.testing.assert_allclose(est.singular_values_(np.float64), s[:k], rtol=2e-4 if f32 else 1e-5)
+    assert O.subspace_angle(est.components_(np.float64), vt[:k]) < (2e-3 if f32 else 1e-4)
+    t = est.transform(A)
+    comps, mean = est.components_(np.float64), est.mean_(np.float64)
+    if masked:
+        tw = O.transform_masked_fast(ptr, idx, val, m, n, comps, mean, True, mask)
+    else:
+        tw = O.transform_sparse(ptr, idx, val, m, n, comps, mean, True)
+    np.testing.assert_allclose(t, tw, atol=(5e-4 if f32 else 1e-9) * max(1.0, float(np.abs(tw).max())))
 
 
 def test_lanczos_vs_oracle_and_rank_error():
