@@ -151,7 +151,84 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   CsrView<T> At;
   const uint64_t* at_packed = nullptr;
   bool at_seg_ready = false;
-  {
+  // a host matrix that came through upload() brought its statistics along (gathered behind the DMA, exact sums)
+  bool from_upload = h.up_stats.valid && A.ptr == h.in_ptr.p && A.idx == h.in_idx.p && A.val == h.in_val.p &&
+                     h.up_stats.m == (uint64_t)m && h.up_stats.n == (uint64_t)n && h.up_stats.nnz == (uint64_t)nnz &&
+                     h.up_stats.dtype == kDtype && n > 0 && !h.comm.active();   // (ranks must not differ in their collectives)
+
+  // A's side of the preparation runs beside the main stream.  Its pieces synchronise with the host (entry counts come
+  // back), so where the main thread has its own synchronising work a helper thread drives them on the side stream:
+  //  * masked fits: the column compaction (MaskedCSRMatrix::new, sparse_masked/mod.rs:313), then the compacted matrix's format;
+  //  * unmasked f32 fits on the staged sweep: A's format, while this thread builds A^T's straight from A (below).
+  bool a_built_aside = false, ok_a_aside = false;
+  std::thread aside;
+  std::exception_ptr aside_err;
+  int64_t nnz_used = 0;
+  struct Joiner {   // (an exception on the main path must not leave the helper running into freed state)
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } joiner{aside};
+  const bool serial = getenv("SAPCA_PREPARE_SERIAL") != nullptr;
+  const bool masked_aside = masked && n_used > 0 && !serial;
+  const bool try_direct = sizeof(T) == 4 && at_tile_major && !masked && !serial;   // A^T's format without a transposed CSR
+  if (masked_aside || try_direct) {
+    if (!h.stream2) {
+      SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
+      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
+      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
+    }
+    SAPCA_HIP(hipEventRecord(h.ev_fork, s));   // A (and the index maps) are on the device
+    h.tiled_a = TiledOp();
+    a_built_aside = true;
+    aside = std::thread([&, n_used, tiled_ldp] {
+      try {
+        SAPCA_HIP(hipSetDevice(h.device));
+        SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
+        CsrView<T> src = A;
+        if (masked) {
+          int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
+          int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+          T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+          k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.tb_a.tmp, h.stream2);
+          h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
+          src = view(h.a_used);
+        }
+        if (tiled_ldp != 0) {
+          if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(src, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+          else ok_a_aside = k::build_tiled(src, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+        }
+        SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));
+      } catch (...) {
+        aside_err = std::current_exception();
+      }
+    });
+  }
+
+  if (from_upload) {
+    // the last chunk's share of those statistics may still be in flight; the accumulators refuse inf/nan (the flag is
+    // final once the side stream has passed up_stats_done): the sums of the transposed matrix take over then
+    SAPCA_HIP(hipEventSynchronize(h.up_stats_done));
+    if (*static_cast<const int*>(h.up_stats.flag.p) != 0) {
+      h.up_stats.valid = false;
+      from_upload = false;
+    }
+  }
+
+  // A^T's tile-major format straight from A (spmm_tiled.hip, "bucket route"): no transposed CSR, no sort; the column
+  // statistics come out of the same pass.  Outside its limits (more than 65536 columns, ...) the transposition takes over.
+  bool at_direct = false;
+  if constexpr (sizeof(T) == 4) {
+    if (try_direct) {
+      Scope sc(h, C_PREPARE);
+      int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
+      double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+      h.tiled_at = TiledOp();
+      at_direct = k::build_tiled_at_direct(A, tiled_ldp, h.tiled_at, h.tb_at, at_ptr, from_upload ? nullptr : d_stats, h.scratch, s);
+      if (at_direct) { At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr; }
+    }
+  }
+
+  if (!at_direct) {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
     int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
@@ -164,77 +241,31 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
   }
 
-  // A's format does not depend on the transposition: build it on a side stream while the sort runs on the
-  // main one (both are memory-latency bound and overlap well); the main stream joins before the first sweep.
-  bool a_built_aside = false, ok_a_aside = false;
-  // Masked fits: A's side is the column compaction (MaskedCSRMatrix::new, sparse_masked/mod.rs:313) and then the format
-  // of the compacted matrix.  Both synchronise with the host (entry counts come back), so a helper thread drives them on
-  // the side stream while this one keeps the main stream fed (statistics, row selection of A^T, A^T's format).
-  std::thread aside;
-  std::exception_ptr aside_err;
-  int64_t nnz_used = 0;
-  struct Joiner {   // (an exception on the main path must not leave the helper running into freed state)
-    std::thread& t;
-    ~Joiner() { if (t.joinable()) t.join(); }
-  } joiner{aside};
-  const bool masked_aside = masked && n_used > 0 && getenv("SAPCA_PREPARE_SERIAL") == nullptr;
-  if (masked_aside) {
+  // (f64, or the serial switch: A's format on the side stream, driven from this thread after the transposition is queued)
+  if (!a_built_aside && tiled_ldp != 0 && !masked && !serial) {
     if (!h.stream2) {
       SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
       SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
       SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
     }
-    SAPCA_HIP(hipEventRecord(h.ev_fork, s));   // A and the index maps are on the device
+    SAPCA_HIP(hipEventRecord(h.ev_fork, s));               // A is ready on the main stream at this point...
+    SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
     h.tiled_a = TiledOp();
+    if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(A, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+    else ok_a_aside = k::build_tiled(A, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
+    SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));       // ...and the main stream waits for it at the end of prepare()
     a_built_aside = true;
-    aside = std::thread([&, n_used, tiled_ldp] {
-      try {
-        SAPCA_HIP(hipSetDevice(h.device));
-        SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
-        int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
-        int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
-        T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-        k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.tb_a.tmp, h.stream2);
-        h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
-        if (tiled_ldp != 0) {
-          if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
-          else ok_a_aside = k::build_tiled(view(h.a_used), tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
-        }
-        SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));
-      } catch (...) {
-        aside_err = std::current_exception();
-      }
-    });
-  }
-  {
-    if (tiled_ldp != 0 && !masked && getenv("SAPCA_PREPARE_SERIAL") == nullptr) {
-      if (!h.stream2) {
-        SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
-        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
-        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
-      }
-      SAPCA_HIP(hipEventRecord(h.ev_fork, s));               // A is ready on the main stream at this point...
-      SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
-      h.tiled_a = TiledOp();
-      if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(A, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
-      else ok_a_aside = k::build_tiled(A, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
-      SAPCA_HIP(hipEventRecord(h.ev_join, h.stream2));       // ...and the main stream waits for it at the end of prepare()
-      a_built_aside = true;
-    }
   }
 
   // R1/R2 (csr.rs:259-312, 558-608) as row sums of A^T, plus the per-column stored-entry count.
   std::vector<double> sums((size_t)2 * n + 1, 0.0);
-  // a host matrix that came through upload() brought its statistics along (gathered behind the DMA, exact sums)
-  const bool from_upload = h.up_stats.valid && A.ptr == h.in_ptr.p && A.idx == h.in_idx.p && A.val == h.in_val.p &&
-                           h.up_stats.m == (uint64_t)m && h.up_stats.n == (uint64_t)n && h.up_stats.nnz == (uint64_t)nnz &&
-                           h.up_stats.dtype == kDtype && n > 0 && !h.comm.active();   // (ranks must not differ in their collectives)
   auto column_statistics = [&](bool uploaded) {
     Scope sc(h, C_STATS);
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
     if (uploaded) {
-      SAPCA_HIP(hipStreamWaitEvent(s, h.up_stats_done, 0));
       SAPCA_HIP(hipMemcpyAsync(d_stats, h.up_stats.out.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    } else if (at_direct) {
+      k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);   // (the sums came out of the format build)
     } else {
       if constexpr (sizeof(T) == 4) {
         // packed tile-major rows: the statistics pass also leaves the A^T builder's per-row tile index behind
@@ -254,11 +285,6 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     SAPCA_HIP(hipStreamSynchronize(s));
   };
   column_statistics(from_upload);
-  // the accumulators refuse inf/nan (the flag is final once the stream has passed up_stats_done): the row sums take over
-  if (from_upload && *static_cast<const int*>(h.up_stats.flag.p) != 0) {
-    h.up_stats.valid = false;
-    column_statistics(false);
-  }
   h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
   const double mg = (double)h.m_global;
 
@@ -304,13 +330,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   // tile-major companions for the LDS-staged sweep
   if (!a_built_aside) h.tiled_a = TiledOp();
-  h.tiled_at = TiledOp();
+  if (!at_direct) h.tiled_at = TiledOp();
   if constexpr (sizeof(T) == 4) {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
       if (!a_built_aside) ok_a_aside = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
       if (!from_at) join_aside();   // (this route reads the compacted A)
-      bool ok_at = (!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
+      bool ok_at = at_direct || (!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
                    k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed, true, at_seg_ready);
       if (at_packed && !ok_at) {   // someone needs the transposed CSR after all
         k::unpack_transposed(at_packed, nnz, const_cast<int32_t*>(At.idx), reinterpret_cast<float*>(const_cast<T*>(At.val)), s);
@@ -324,7 +350,16 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         fprintf(stderr, "sapca: tile-major formats: A %s (nrb %d, nct %d, split %d, %lld entries), A^T %s (nrb %d, nct %d, split %d, %lld entries)\n",
                 ok_a ? "ok" : "no", h.tiled_a.nrb, h.tiled_a.nct, h.tiled_a.nsplit, (long long)h.tiled_a.total_entries,
                 ok_at ? "ok" : "no", h.tiled_at.nrb, h.tiled_at.nct, h.tiled_at.nsplit, (long long)h.tiled_at.total_entries);
-      if (!ok_a || !ok_at) { h.tiled_a = TiledOp(); h.tiled_at = TiledOp(); }
+      if (!ok_a || !ok_at) {
+        h.tiled_a = TiledOp();
+        h.tiled_at = TiledOp();
+        if (at_direct) {   // the row kernel reads a transposed CSR, which the bucket route never made
+          int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+          T* at_val = h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+          k::transpose_csr(A, h.at_ptr.as<int64_t>((size_t)n + 1), at_idx, at_val, h.scratch, s, 0, nullptr);
+          h.at_used = {n, m, nnz, h.at_ptr.p, at_idx, at_val};
+        }
+      }
     }
   } else {
     if (tiled_ldp != 0 && n_used > 0) {

@@ -86,6 +86,13 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
 // The same format with f64 values for panels of 64 f64 columns (512-byte rows: the tile geometry of the
 // 128-float panels); built from a CSR in natural row order by the direct fill.
 bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
+// The format of A^T (op: A.cols x A.rows) straight from A, without a transposed CSR: a histogram per (tile of A rows,
+// column), a scatter of A's entries into per-chunk buckets, one workgroup per chunk for the format.  Byte-identical to
+// build_tiled on the tile-major transposition.  at_ptr (A.cols + 1) receives A^T's row offsets, stats (2 * A.cols, may
+// be null) the column sums and sums of squares of A, added per tile and then in tile order.  Returns false (nothing
+// usable built) when the operator is outside this route's limits: the caller transposes instead.
+bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, int64_t* at_ptr, double* stats,
+                           DevBuf& scratch, hipStream_t s);
 // Column statistics of A (row sums / sums of squares of the packed tile-major A^T rows, same summation order as
 // row_sums) and, in the same pass, the per-row tile index build_tiled(..., rows_tile_major, packed, ., seg_ready) needs.
 void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, int64_t cols, int ldp, TiledBuffers& buf,

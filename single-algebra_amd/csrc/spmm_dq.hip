@@ -49,10 +49,10 @@ typedef float v8f __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(DQ_THREADS)
 dq_desc_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __restrict__ chunk_off,
                const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, int rg, uint8_t* __restrict__ desc,
-               uint32_t* __restrict__ info, int* __restrict__ max_nch) {
-  const int64_t cidx = blockIdx.x;
-  const int rb = (int)(cidx / nct), t = (int)(cidx % nct);
+               uint32_t* __restrict__ info, int* __restrict__ max_nch, int64_t nchunks) {
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  for (int64_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {   // (a chunk is a few hundred bytes of tables: several per workgroup)
+  const int rb = (int)(cidx / nct), t = (int)(cidx % nct);
   const int nrows = blk_row0[rb + 1] - blk_row0[rb];
   const int nquads = (nrows + 3) / 4;
   const int quad0 = dq_first(wave, nquads), my_quads = dq_first(wave + 1, nquads) - quad0;
@@ -83,6 +83,7 @@ dq_desc_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __r
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) j += (jj < my_quads && cj[jj] <= step) ? 1 : 0;
     d[p] = (uint8_t)(step < N ? 4 * j : 4 * rg);
+  }
   }
 }
 
@@ -182,8 +183,8 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   uint32_t* d_info = buf.dq_info.as<uint32_t>(info_words + 4);
   int* d_max = reinterpret_cast<int*>(d_info + info_words);
   SAPCA_HIP(hipMemsetAsync(d_info + (size_t)nchunks * DQ_WAVES * 2, 0, (64 * 2 + 4) * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(dq_desc_kernel, dim3((unsigned)nchunks), dim3(DQ_THREADS), 0, s, op.blk_row0, op.nct, op.chunk_off, op.wave_off,
-                     reinterpret_cast<const uint16_t*>(op.steps), rg, d_desc, d_info, d_max);
+  hipLaunchKernelGGL(dq_desc_kernel, dim3((unsigned)std::min<int64_t>(nchunks, 2048)), dim3(DQ_THREADS), 0, s, op.blk_row0, op.nct,
+                     op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps), rg, d_desc, d_info, d_max, nchunks);
   SAPCA_HIP(hipGetLastError());
   // (a wave's stream in one tile may be any length: the sweep reloads its descriptor register every 32 chunks.  The chunk
   // count shares its table word with the tail length: 16 bits, i.e. 1M steps of one wave in one tile, cannot be reached

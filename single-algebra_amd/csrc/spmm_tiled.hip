@@ -436,16 +436,27 @@ tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 __global__ void __launch_bounds__(QBLOCK_ROWS)
 quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm,
                   int nct, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
-                  int64_t* __restrict__ chunk_size) {
+                  int64_t* __restrict__ chunk_size, const uint16_t* __restrict__ cnt16 = nullptr, int64_t cnt_stride = 0,
+                  int64_t* __restrict__ raw_size = nullptr) {
   __shared__ uint32_t scan[QBLOCK_ROWS];
+  __shared__ uint32_t raw_total;
   const int rb = blockIdx.x / nct, ct = blockIdx.x % nct;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
   const int lr = threadIdx.x;   // local row; its quad is lr / 4
   int len = 0;
+  if (lr == 0) raw_total = 0;
   if (lr < nrows) {
     const int64_t r = perm ? (int64_t)perm[row0 + lr] : (int64_t)row0 + lr;   // slot -> row (rows sorted by length)
-    len = seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
+    // (the bucket builder of A^T counts entries per (tile, row) instead of indexing a transposed CSR)
+    len = cnt16 ? (int)cnt16[(int64_t)ct * cnt_stride + r] : seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
+  }
+  if (raw_size) {
+    int w = len;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) w += __shfl_xor(w, off);
+    __syncthreads();
+    if ((lr & (WAVE - 1)) == 0 && w) atomicAdd(&raw_total, (uint32_t)w);
   }
   int qmax = max(len, __shfl_xor(len, 1));
   qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
@@ -465,7 +476,10 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
     const int first_row = 4 * q_first(lr, nquads);
     wave_off[(int64_t)blockIdx.x * QWAVES + lr] = first_row > 0 ? scan[first_row - 1] : 0u;
   }
-  if (lr == QBLOCK_ROWS - 1) chunk_size[blockIdx.x] = scan[lr];
+  if (lr == QBLOCK_ROWS - 1) {
+    chunk_size[blockIdx.x] = scan[lr];
+    if (raw_size) raw_size[blockIdx.x] = raw_total;   // (the scan's barriers ordered the atomics before this read)
+  }
 }
 
 // one wave per row: the k-th entry (in column order) that the row has in tile t goes to slot
@@ -1320,6 +1334,246 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
                      ncols, cvec, mode);
 }
 
+
+// ---- A^T's format straight from A through per-chunk buckets (no transposed CSR, no sort) -----------------------
+// The transposition route moves every entry five times (pack, two radix passes, statistics, fill).  Here a histogram
+// pass counts the entries of every (tile of A rows, column), which is all the quad counting needs; a scatter pass drops
+// every entry of A into the bucket of its chunk (block of A^T rows, tile) as {slot in the block, row in the tile, value};
+// one workgroup per chunk then ranks the entries of every A^T row by their row in the tile with per-slot bit masks (the
+// ranks of the column-sorted transposed row) and writes the chunk's region of the format, padding included.  The bytes
+// are those of the other routes.  The column statistics come from the finished chunks: every (tile, A^T row) segment is
+// summed in its stored order, the per-tile partial sums are added in tile order (a fixed order: reproducible).
+constexpr int ATD_MAX_COLS = 65536;       // the histogram keeps two 16-bit counters per LDS word
+constexpr int ATD_THREADS = 1024;
+constexpr int ATD_MASK_WORDS = 10;        // 320 rows of a tile
+
+__global__ void __launch_bounds__(ATD_THREADS)
+atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
+                uint16_t* __restrict__ cnt16) {
+  extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
+  const int t = blockIdx.x;
+  const int nw = (int)(n2 / 2);
+  for (int i = threadIdx.x; i < nw; i += ATD_THREADS) atd_h32[i] = 0u;
+  __syncthreads();
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  for (int i = wave; i < tc; i += ATD_THREADS / WAVE) {
+    const int64_t r = (int64_t)t + (int64_t)i * nct;
+    if (r >= m) break;
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t eb = ptr[r] + lane; eb < e1; eb += 8 * WAVE) {   // eight loads in flight per lane
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = eb + u * WAVE < e1 ? idx[eb + u * WAVE] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c[u] >= 0) atomicAdd(&atd_h32[c[u] >> 1], 1u << (16 * (c[u] & 1)));   // (at most 320 rows per tile: no carry into the neighbour)
+    }
+  }
+  __syncthreads();
+  uint32_t* out = reinterpret_cast<uint32_t*>(cnt16 + (int64_t)t * n2);
+  for (int i = threadIdx.x; i < nw; i += ATD_THREADS) out[i] = atd_h32[i];
+}
+
+// len[c] = entries of column c (summed over the tiles); the caller scans it into A^T's row offsets.
+// A workgroup takes 64 columns, its 16 waves a sixteenth of the tiles each.
+__global__ void __launch_bounds__(1024)
+atd_rowlen_kernel(const uint16_t* __restrict__ cnt16, int64_t n, int64_t n2, int nct, int64_t* __restrict__ len) {
+  __shared__ uint32_t part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (nct + 15) / 16;
+  uint32_t a = 0;
+  if (c < n)
+    for (int t = grp * per; t < min(nct, (grp + 1) * per); ++t) a += cnt16[(int64_t)t * n2 + c];
+  part[grp][lane] = a;
+  __syncthreads();
+  if (grp == 0 && c <= n) {
+    int64_t total = 0;
+    if (c < n)
+      for (int g = 0; g < 16; ++g) total += part[g][lane];
+    len[c] = total;   // (len[n] = 0: the scan turns it into the total)
+  }
+}
+
+// colmap[row of A^T] = block << 10 | slot inside the block
+__global__ void atd_colmap_kernel(const int32_t* __restrict__ blk, int nrb, const uint32_t* __restrict__ perm, int64_t rows,
+                                  uint32_t* __restrict__ colmap) {
+  const int64_t sp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sp >= rows) return;
+  int lo = 0, hi = nrb;   // last block with blk[b] <= sp
+  while (lo + 1 < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)blk[mid] <= sp) lo = mid; else hi = mid;
+  }
+  const int64_t row = perm ? (int64_t)perm[sp] : sp;
+  colmap[row] = ((uint32_t)lo << 10) | (uint32_t)(sp - blk[lo]);
+}
+
+// one workgroup per tile of A rows: its entries go to the buckets (block of their column, this tile)
+__global__ void __launch_bounds__(ATD_THREADS)
+atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val, int64_t m, int nct,
+                   int tc, const uint32_t* __restrict__ colmap, int nrb, const int64_t* __restrict__ bucket_off,
+                   uint2* __restrict__ bucket) {
+  extern __shared__ uint32_t atd_cur[];   // [nrb] entries written to bucket (rb, t) so far, then [nrb] bucket starts (int64)
+  int64_t* atd_base = reinterpret_cast<int64_t*>(atd_cur + ((nrb + 1) & ~1));
+  const int t = blockIdx.x;
+  for (int i = threadIdx.x; i < nrb; i += ATD_THREADS) {
+    atd_cur[i] = 0u;
+    atd_base[i] = bucket_off[(int64_t)i * nct + t];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  for (int i = wave; i < tc; i += ATD_THREADS / WAVE) {
+    const int64_t r = (int64_t)t + (int64_t)i * nct;
+    if (r >= m) break;
+    const int64_t e1 = ptr[r + 1];
+    for (int64_t eb = ptr[r]; eb < e1; eb += 4 * WAVE) {   // four batches of 64 entries in flight
+      int cc[4];
+      uint32_t cmv[4];
+      float vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t e = eb + u * WAVE + lane;
+        cc[u] = e < e1 ? idx[e] : -1;
+        vv[u] = e < e1 ? val[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cmv[u] = cc[u] >= 0 ? colmap[cc[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool valid = cc[u] >= 0;
+        const uint32_t cm = cmv[u];
+        const int rb = (int)(cm >> 10);
+        const uint32_t key = ((cm & 1023u) << 9) | (uint32_t)i;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {   // one LDS atomic per run of lanes bound for the same bucket (columns ascend along the row: a few runs)
+          const int lead = __builtin_ctzll(todo);
+          const int rb0 = __shfl(rb, lead);
+          const unsigned long long mine = __ballot(valid && rb == rb0);
+          uint32_t base = 0u;
+          if (lane == lead) base = atomicAdd(&atd_cur[rb0], (uint32_t)__builtin_popcountll(mine));
+          base = __shfl(base, lead);
+          if (valid && rb == rb0) {
+            const uint32_t pos = base + (uint32_t)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
+            bucket[atd_base[rb0] + pos] = make_uint2(key, __float_as_uint(vv[u]));
+          }
+          todo &= ~mine;
+        }
+      }
+    }
+  }
+}
+
+// one workgroup per chunk: ranks from per-slot bit masks over the tile's rows, the chunk's region of the format,
+// the partial column sums of this tile
+__global__ void __launch_bounds__(ATD_THREADS)
+atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bucket_off, const int32_t* __restrict__ blk_row0,
+                const uint32_t* __restrict__ perm, int nct, int ldp_bytes, const int64_t* __restrict__ chunk_off,
+                const uint32_t* __restrict__ quad_off, const uint16_t* __restrict__ steps, Ent* __restrict__ ent,
+                double* __restrict__ psum, double* __restrict__ psq, int64_t n) {
+  __shared__ uint32_t mask[QBLOCK_ROWS * ATD_MASK_WORDS];
+  __shared__ uint32_t qoff_s[Q_BLOCK_QUADS];
+  __shared__ uint16_t steps_s[Q_BLOCK_QUADS];
+  const int64_t chunk = blockIdx.x;
+  const int rb = (int)(chunk / nct), t = (int)(chunk % nct);
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  const int nquads = (nrows + 3) / 4;
+  for (int i = threadIdx.x; i < QBLOCK_ROWS * ATD_MASK_WORDS; i += ATD_THREADS) mask[i] = 0u;
+  if (threadIdx.x < Q_BLOCK_QUADS) {
+    const int q = threadIdx.x;
+    qoff_s[q] = q < nquads ? quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + t] : 0u;
+    steps_s[q] = q < nquads ? steps[chunk * Q_BLOCK_QUADS + q] : (uint16_t)0;
+  }
+  __syncthreads();
+  const int64_t b0 = bucket_off[chunk], b1 = bucket_off[chunk + 1];
+  Ent* dst = ent + chunk_off[chunk];
+  constexpr int HOLD = 12;   // entries a thread keeps in registers (chunks of up to 12288 entries: one read of the bucket)
+  uint2 kv[HOLD];
+#pragma unroll
+  for (int u = 0; u < HOLD; ++u) {
+    const int64_t e = b0 + threadIdx.x + (int64_t)u * ATD_THREADS;
+    kv[u] = e < b1 ? bucket[e] : make_uint2(0xffffffffu, 0u);
+  }
+#pragma unroll
+  for (int u = 0; u < HOLD; ++u)
+    if (kv[u].x != 0xffffffffu) {
+      const uint32_t slot = kv[u].x >> 9, i = kv[u].x & 511u;
+      atomicOr(&mask[slot * ATD_MASK_WORDS + (i >> 5)], 1u << (i & 31u));
+    }
+  for (int64_t e = b0 + threadIdx.x + (int64_t)HOLD * ATD_THREADS; e < b1; e += ATD_THREADS) {   // (longer chunks: the rest from memory)
+    const uint32_t key = bucket[e].x;
+    const uint32_t slot = key >> 9, i = key & 511u;
+    atomicOr(&mask[slot * ATD_MASK_WORDS + (i >> 5)], 1u << (i & 31u));
+  }
+  __syncthreads();
+  auto place = [&](const uint2 e) {
+    const uint32_t slot = e.x >> 9, i = e.x & 511u;
+    const uint32_t* mk = mask + slot * ATD_MASK_WORDS;
+    uint32_t rank = __builtin_popcount(mk[i >> 5] & ((1u << (i & 31u)) - 1u));
+    for (uint32_t w = 0; w < (i >> 5); ++w) rank += __builtin_popcount(mk[w]);
+    Ent x;
+    x.off = i * (uint32_t)ldp_bytes;
+    x.val = __uint_as_float(e.y);
+    dst[qoff_s[slot >> 2] + rank * 4u + (slot & 3u)] = x;
+  };
+#pragma unroll
+  for (int u = 0; u < HOLD; ++u)
+    if (kv[u].x != 0xffffffffu) place(kv[u]);
+  for (int64_t e = b0 + threadIdx.x + (int64_t)HOLD * ATD_THREADS; e < b1; e += ATD_THREADS) place(bucket[e]);
+  // padding of this thread's slot, then its partial sums from the finished segment
+  const int slot = threadIdx.x;
+  int len = 0;
+  if (slot < 4 * nquads) {
+#pragma unroll
+    for (int w = 0; w < ATD_MASK_WORDS; ++w) len += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
+    const uint32_t o = qoff_s[slot >> 2] + (uint32_t)(slot & 3);
+    for (int k = len; k < (int)steps_s[slot >> 2]; ++k) dst[o + 4u * k] = Ent{0u, 0.f};
+  }
+  if (!psum) return;
+  __threadfence_block();   // (workgroup scope: the segments are read back by the workgroup that wrote them; an agent-scope
+  __syncthreads();         //  fence writes the whole L2 back on this part -- measured: 12 ms instead of 0.7 for the kernel)
+  if (slot < nrows) {
+    const uint32_t o = qoff_s[slot >> 2] + (uint32_t)(slot & 3);
+    double a = 0, b = 0;
+    for (int k = 0; k < len; ++k) {
+      const double v = (double)dst[o + 4u * k].val;
+      a += v;
+      b += v * v;
+    }
+    const int64_t row = perm ? (int64_t)perm[row0 + slot] : (int64_t)row0 + slot;
+    psum[(int64_t)t * n + row] = a;
+    psq[(int64_t)t * n + row] = b;
+  }
+}
+
+// sum[c] = the per-tile partial sums of column c added in a fixed order: sixteen runs of consecutive tiles, then the runs
+__global__ void __launch_bounds__(1024)
+atd_stats_reduce_kernel(const double* __restrict__ psum, const double* __restrict__ psq, int64_t n, int nct,
+                        double* __restrict__ sum, double* __restrict__ sumsq) {
+  __shared__ double pa[16][64], pb[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (nct + 15) / 16;
+  double a = 0, b = 0;
+  if (c < n)
+    for (int t = grp * per; t < min(nct, (grp + 1) * per); ++t) {
+      a += psum[(int64_t)t * n + c];
+      b += psq[(int64_t)t * n + c];
+    }
+  pa[grp][lane] = a;
+  pb[grp][lane] = b;
+  __syncthreads();
+  if (grp == 0 && c < n) {
+    double x = 0, y = 0;
+    for (int g = 0; g < 16; ++g) {
+      x += pa[g][lane];
+      y += pb[g][lane];
+    }
+    sum[c] = x;
+    sumsq[c] = y;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------- host side
@@ -1327,9 +1581,19 @@ namespace {
 // VT = float: every route below.  VT = double: the quad format through the direct fill only (the tile-major /
 // packed-row routes and the LDS-staged fill carry f32 values); its 64-column panel rows are 512 bytes, so
 // the geometry is that of the 128-float panels -- `ldp` below is the row length in FLOAT units.
+// the bucket route to A^T's format: S describes A^T (row offsets only), the entries come from A itself
+struct AtDirectSrc {
+  const CsrView<float>* A;
+  const uint16_t* cnt16;   // [tile][column] entry counts, row stride n2
+  int64_t n2;
+  DevBuf* scratch;         // buckets, bucket offsets, column map, partial sums
+  double* stats;           // out: sum | sumsq per column of A (may be null)
+};
+
 template <typename VT>
 bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp& op, TiledBuffers& buf, hipStream_t s,
-                   bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready) {
+                   bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready,
+                   const AtDirectSrc* direct = nullptr) {
   typedef typename EntOf<VT>::type E;
   constexpr bool f32 = sizeof(VT) == 4;
   const int ldp = ldp_elems * (int)sizeof(VT) / 4;
@@ -1393,7 +1657,9 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   if (quad && !transposed && (op_cols >= (1 << 24) || nct > (rows_tile_major ? Q_MAX_TILES_RUNS : 4096))) return false;   // float-reciprocal tile arithmetic, LDS tables of the builders
   const float inv_nct = 1.0f / (float)nct;
   int32_t* d_seg = nullptr;
-  if (!transposed) {
+  if (direct && !(f32 && quad && !transposed && rows_tile_major && dq_candidate && tc <= 32 * ATD_MASK_WORDS && block_rows <= QBLOCK_ROWS))
+    return false;
+  if (!transposed && !direct) {
     d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nct + 1));
     if (quad && rows_tile_major && seg_ready) {
       // at_stats_index() filled it in the statistics pass
@@ -1449,6 +1715,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   uint32_t* d_quad_off = nullptr;
   uint16_t* d_rank = nullptr;
   int64_t* d_chunk = nullptr;
+  int64_t* d_raw = nullptr;   // (bucket route) stored entries per chunk, then their exclusive scan
   for (int attempt = 0;; ++attempt) {
     tiles_per_split = (nct + nsplit - 1) / nsplit;
     nsplit = (nct + tiles_per_split - 1) / tiles_per_split;
@@ -1490,6 +1757,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       hipLaunchKernelGGL(tquad_count_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS),
                          (size_t)2 * QBLOCK_ROWS * maskw * sizeof(uint32_t), s, S.ptr, S.idx, d_seg, S.rows, d_blk, (int)nrb, nct,
                          maskw, d_rank, reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
+    } else if (quad && direct) {
+      d_raw = buf.rank.as<int64_t>((size_t)nchunks + 1);
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(QBLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
+                         reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk, direct->cnt16, direct->n2, d_raw);
     } else if (quad)
       hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(QBLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
@@ -1536,8 +1807,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                            (double)total <= 0.85 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
-  if (packed_rows && !runs_fill) return false;
-  if (staged_fill || runs_fill) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)ENT_SLACK * sizeof(E), s));
+  if ((packed_rows || direct) && !runs_fill) return false;
+  if (staged_fill || runs_fill || direct) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)ENT_SLACK * sizeof(E), s));
   else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + ENT_SLACK) * sizeof(E), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
   uint32_t* run_global = nullptr;
@@ -1546,7 +1817,31 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     lds = 0;
   }
   if constexpr (f32) {
-  if (transposed)
+  if (direct) {
+    // bucket offsets, column -> (block, slot), the scatter of A's entries, one workgroup per chunk for the format
+    const CsrView<float>& A = *direct->A;
+    SAPCA_HIP(hipMemsetAsync(d_raw + nchunks, 0, sizeof(int64_t), s));
+    size_t scan_bytes = 0;
+    SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_raw, d_raw, (int64_t)0, (size_t)nchunks + 1, rocprim::plus<int64_t>(), s));
+    const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = round_up((size_t)A.nnz * sizeof(uint2), 256);
+    const size_t a_part = direct->stats ? round_up((size_t)nct * op_rows * sizeof(double), 256) : 0;
+    char* base = static_cast<char*>(direct->scratch->ensure(a_col + a_bucket + 2 * a_part + scan_bytes + 256));
+    uint32_t* d_colmap = reinterpret_cast<uint32_t*>(base);
+    uint2* d_bucket = reinterpret_cast<uint2*>(base + a_col);
+    double* d_psum = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket) : nullptr;
+    double* d_psq = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket + a_part) : nullptr;
+    void* scan_tmp = base + a_col + a_bucket + 2 * a_part;
+    SAPCA_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, d_raw, d_raw, (int64_t)0, (size_t)nchunks + 1, rocprim::plus<int64_t>(), s));
+    hipLaunchKernelGGL(atd_colmap_kernel, dim3((unsigned)((op_rows + 255) / 256)), dim3(256), 0, s, d_blk, (int)nrb, d_perm, op_rows,
+                       d_colmap);
+    hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)nct), dim3(ATD_THREADS), (size_t)(nrb + 2) * 12, s, A.ptr, A.idx, A.val,
+                       A.rows, nct, tc, d_colmap, (int)nrb, d_raw, d_bucket);
+    hipLaunchKernelGGL(atd_fill_kernel, dim3((unsigned)nchunks), dim3(ATD_THREADS), 0, s, d_bucket, d_raw, d_blk, d_perm, nct, ldp * 4,
+                       d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent, d_psum, d_psq, op_rows);
+    if (direct->stats)
+      hipLaunchKernelGGL(atd_stats_reduce_kernel, dim3((unsigned)((op_rows + 63) / 64)), dim3(1024), 0, s, d_psum, d_psq, op_rows, nct,
+                         direct->stats, direct->stats + op_rows);
+  } else if (transposed)
     hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (runs_fill) {
@@ -1605,6 +1900,33 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
 }
 bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   return build_tiled_t<double>(S, false, ldp, op, buf, s, false, nullptr, true, false);
+}
+
+bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, int64_t* at_ptr, double* stats,
+                           DevBuf& scratch, hipStream_t s) {
+  op = TiledOp();
+  const bool off = getenv("SAPCA_AT_SORT") != nullptr;   // A/B: the transposition (radix sort) route
+  if (off || ldp != 64 || A.rows == 0 || A.cols == 0 || A.nnz == 0 || A.cols > ATD_MAX_COLS || A.rows >= (1 << 24)) return false;
+  const int64_t m = A.rows, n = A.cols;
+  const int tc = Q_TILE_BYTES / (ldp * 4);
+  const int nct = tiled_tile_count(m, ldp);
+  if (tc > 32 * ATD_MASK_WORDS || nct > Q_MAX_TILES_RUNS) return false;
+  const int64_t n2 = round_up(n, 2);
+  // entry counts per (tile of A rows, column); their column totals are A^T's row lengths
+  uint16_t* cnt16 = buf.seg.as<uint16_t>((size_t)nct * n2);   // (takes the place of the per-row tile index of the other routes)
+  static LdsAttrState hist_attr;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), (size_t)n2 * 2, hist_attr);
+  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3(ATD_THREADS), (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
+  hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
+  size_t scan_bytes = 0;
+  SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, at_ptr, at_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), s));
+  void* tmp = buf.tmp.ensure(scan_bytes + 256);
+  SAPCA_HIP(rocprim::exclusive_scan(tmp, scan_bytes, at_ptr, at_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), s));
+  SAPCA_HIP(hipGetLastError());
+  CsrView<float> At;
+  At.rows = n; At.cols = m; At.nnz = A.nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr;
+  AtDirectSrc src{&A, cnt16, n2, &scratch, stats};
+  return build_tiled_t<float>(At, false, ldp, op, buf, s, true, nullptr, true, false, &src);
 }
 
 void at_stats_index(const int64_t* ptr, const uint64_t* packed, int64_t rows, int64_t cols, int ldp, TiledBuffers& buf,

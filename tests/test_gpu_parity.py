@@ -949,20 +949,28 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.05, k, seed=5, dtype=torch.float32))
     om = synth.gaussian_panel(n, k + p, 3).numpy()
     out = []
-    routes = (None, "SAPCA_AT_UNPACK", "SAPCA_AT_NATURAL", "SAPCA_TILED_FROM_A")
+    routes = ("SAPCA_AT_SORT", "SAPCA_AT_UNPACK", "SAPCA_AT_NATURAL", "SAPCA_TILED_FROM_A", None)
     monkeypatch.setenv("SAPCA_TILE_DEFAULT", "1")   # same LDS split on every route (a natural-order A^T could take the bigger tile)
     monkeypatch.setenv("SAPCA_NO_ROWSORT", "1")     # and the same row order: the builder straight from A does not sort rows by length
     for route in routes:
-        for r in routes[1:]:
+        for r in routes[:-1]:
             monkeypatch.delenv(r, raising=False)
         if route:
             monkeypatch.setenv(route, "1")
+            if route != "SAPCA_AT_SORT":
+                monkeypatch.setenv("SAPCA_AT_SORT", "1")   # the other switches select among the transposition's routes
         pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
-        t = pca.fit_transform(mat(ptr, idx, val, m, n))
+        dev = sapca.DeviceCsr(*(torch.as_tensor(x, device="cuda") for x in (ptr.astype(np.int64), idx.astype(np.int32), val)), (m, n))
+        t = pca.fit_transform(dev).cpu().numpy()     # (device arrays: every route computes its own column statistics)
         out.append((pca.singular_values_(np.float64), pca.components_(np.float64), t, pca.mean_(np.float64)))
-    for o in out[1:]:
+    for o in out[1:-1]:
         for a, b in zip(out[0], o):
             np.testing.assert_array_equal(a, b)
+    # the default (bucket) route writes the same format bytes, but adds the column statistics per tile and then over the
+    # tiles instead of along the transposed rows: means equal to f64 rounding, hence the same model to f32 rounding
+    np.testing.assert_allclose(out[-1][3], out[0][3], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(out[-1][0], out[0][0], rtol=1e-5)
+    np.testing.assert_allclose(out[-1][2], out[0][2], atol=1e-4 * np.abs(out[0][2]).max())
     want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
 
