@@ -462,14 +462,19 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
   qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
   const uint32_t padded = (lr & 3) == 0 ? (uint32_t)qmax * 4u : 0u;
   if ((lr & 3) == 0) steps[(int64_t)blockIdx.x * Q_BLOCK_QUADS + lr / 4] = (uint16_t)qmax;
-  scan[lr] = padded;
-  __syncthreads();
-  for (int off = 1; off < QBLOCK_ROWS; off <<= 1) {
-    uint32_t v = lr >= off ? scan[lr - off] : 0;
-    __syncthreads();
-    scan[lr] += v;
-    __syncthreads();
+  // inclusive scan of the padded quad sizes over the block: inside each wave by shuffles, the 16 wave totals through LDS
+  __shared__ uint32_t wave_total[QBLOCK_ROWS / WAVE];
+  uint32_t inc = padded;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const uint32_t y = __shfl_up(inc, off);
+    if ((lr & (WAVE - 1)) >= off) inc += y;
   }
+  if ((lr & (WAVE - 1)) == WAVE - 1) wave_total[lr / WAVE] = inc;
+  __syncthreads();
+  for (int w = 0; w < lr / WAVE; ++w) inc += wave_total[w];
+  scan[lr] = inc;
+  __syncthreads();
   // [row block][quad][tile]: the builder reads one quad's offsets in all tiles contiguously
   if ((lr & 3) == 0 && lr / 4 < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + lr / 4) * nct + ct] = scan[lr] - padded;
   if (lr < QWAVES) {
@@ -1427,20 +1432,22 @@ atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
     const int64_t r = (int64_t)t + (int64_t)i * nct;
     if (r >= m) break;
     const int64_t e1 = ptr[r + 1];
-    for (int64_t eb = ptr[r]; eb < e1; eb += 4 * WAVE) {   // four batches of 64 entries in flight
-      int cc[4];
-      uint32_t cmv[4];
-      float vv[4];
+    constexpr int UB = 10;   // batches of 64 entries in flight: a typical row (a few hundred entries) in one round trip
+    for (int64_t eb = ptr[r]; eb < e1; eb += UB * WAVE) {
+      int cc[UB];
+      uint32_t cmv[UB];
+      float vv[UB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UB; ++u) {
         const int64_t e = eb + u * WAVE + lane;
         cc[u] = e < e1 ? idx[e] : -1;
         vv[u] = e < e1 ? val[e] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cmv[u] = cc[u] >= 0 ? colmap[cc[u]] : 0u;
+      for (int u = 0; u < UB; ++u) cmv[u] = cc[u] >= 0 ? colmap[cc[u]] : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UB; ++u) {
+        if (eb + u * WAVE >= e1) break;
         const bool valid = cc[u] >= 0;
         const uint32_t cm = cmv[u];
         const int rb = (int)(cm >> 10);
@@ -1464,30 +1471,33 @@ atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
   }
 }
 
-// one workgroup per chunk: ranks from per-slot bit masks over the tile's rows, the chunk's region of the format,
-// the partial column sums of this tile
-__global__ void __launch_bounds__(ATD_THREADS)
+// one workgroup per chunk: ranks from per-slot bit masks over the tile's rows, the chunk's region of the format
+// assembled in LDS a few dozen quads at a time (written out in whole lines, padding included), the partial column sums
+// of this tile from the assembled segments
+constexpr int ATD_STAGE_ENT = 4096;   // entries of the LDS image (a quad holds at most 4 x 320)
+
+__global__ void __launch_bounds__(ATD_THREADS, 8)   // 64 VGPRs: two workgroups per CU
 atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bucket_off, const int32_t* __restrict__ blk_row0,
                 const uint32_t* __restrict__ perm, int nct, int ldp_bytes, const int64_t* __restrict__ chunk_off,
                 const uint32_t* __restrict__ quad_off, const uint16_t* __restrict__ steps, Ent* __restrict__ ent,
                 double* __restrict__ psum, double* __restrict__ psq, int64_t n) {
   __shared__ uint32_t mask[QBLOCK_ROWS * ATD_MASK_WORDS];
-  __shared__ uint32_t qoff_s[Q_BLOCK_QUADS];
-  __shared__ uint16_t steps_s[Q_BLOCK_QUADS];
+  __shared__ __attribute__((aligned(16))) Ent stage[ATD_STAGE_ENT];
+  __shared__ uint32_t qoff_s[Q_BLOCK_QUADS + 1];
   const int64_t chunk = blockIdx.x;
   const int rb = (int)(chunk / nct), t = (int)(chunk % nct);
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
   for (int i = threadIdx.x; i < QBLOCK_ROWS * ATD_MASK_WORDS; i += ATD_THREADS) mask[i] = 0u;
-  if (threadIdx.x < Q_BLOCK_QUADS) {
+  const uint32_t chunk_entries = (uint32_t)(chunk_off[chunk + 1] - chunk_off[chunk]);
+  if (threadIdx.x <= Q_BLOCK_QUADS) {
     const int q = threadIdx.x;
-    qoff_s[q] = q < nquads ? quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + t] : 0u;
-    steps_s[q] = q < nquads ? steps[chunk * Q_BLOCK_QUADS + q] : (uint16_t)0;
+    qoff_s[q] = q < nquads ? quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + t] : chunk_entries;
   }
   __syncthreads();
   const int64_t b0 = bucket_off[chunk], b1 = bucket_off[chunk + 1];
   Ent* dst = ent + chunk_off[chunk];
-  constexpr int HOLD = 12;   // entries a thread keeps in registers (chunks of up to 12288 entries: one read of the bucket)
+  constexpr int HOLD = 10;   // entries a thread keeps in registers (chunks of up to 10240 entries: one read of the bucket)
   uint2 kv[HOLD];
 #pragma unroll
   for (int u = 0; u < HOLD; ++u) {
@@ -1506,43 +1516,74 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
     atomicOr(&mask[slot * ATD_MASK_WORDS + (i >> 5)], 1u << (i & 31u));
   }
   __syncthreads();
-  auto place = [&](const uint2 e) {
-    const uint32_t slot = e.x >> 9, i = e.x & 511u;
+  // rank of an entry inside its (A^T row, tile) segment = the rows of the tile before its own that hold the column
+  auto rank_of = [&](uint32_t slot, uint32_t i) {
     const uint32_t* mk = mask + slot * ATD_MASK_WORDS;
     uint32_t rank = __builtin_popcount(mk[i >> 5] & ((1u << (i & 31u)) - 1u));
     for (uint32_t w = 0; w < (i >> 5); ++w) rank += __builtin_popcount(mk[w]);
-    Ent x;
-    x.off = i * (uint32_t)ldp_bytes;
-    x.val = __uint_as_float(e.y);
-    dst[qoff_s[slot >> 2] + rank * 4u + (slot & 3u)] = x;
+    return rank;
   };
 #pragma unroll
-  for (int u = 0; u < HOLD; ++u)
-    if (kv[u].x != 0xffffffffu) place(kv[u]);
-  for (int64_t e = b0 + threadIdx.x + (int64_t)HOLD * ATD_THREADS; e < b1; e += ATD_THREADS) place(bucket[e]);
-  // padding of this thread's slot, then its partial sums from the finished segment
-  const int slot = threadIdx.x;
-  int len = 0;
-  if (slot < 4 * nquads) {
-#pragma unroll
-    for (int w = 0; w < ATD_MASK_WORDS; ++w) len += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
-    const uint32_t o = qoff_s[slot >> 2] + (uint32_t)(slot & 3);
-    for (int k = len; k < (int)steps_s[slot >> 2]; ++k) dst[o + 4u * k] = Ent{0u, 0.f};
+  for (int u = 0; u < HOLD; ++u) {   // kept beside the key (bits 19..27): the loop over the image below only places
+    if (kv[u].x != 0xffffffffu) kv[u].x |= rank_of(kv[u].x >> 9, kv[u].x & 511u) << 19;
+    asm volatile("" ::: "memory");   // (one entry's LDS reads at a time: twelve unrolled copies in flight cost 128 VGPRs)
   }
-  if (!psum) return;
-  __threadfence_block();   // (workgroup scope: the segments are read back by the workgroup that wrote them; an agent-scope
-  __syncthreads();         //  fence writes the whole L2 back on this part -- measured: 12 ms instead of 0.7 for the kernel)
-  if (slot < nrows) {
-    const uint32_t o = qoff_s[slot >> 2] + (uint32_t)(slot & 3);
-    double a = 0, b = 0;
-    for (int k = 0; k < len; ++k) {
-      const double v = (double)dst[o + 4u * k].val;
-      a += v;
-      b += v * v;
+  for (int q0 = 0; q0 < nquads;) {
+    // the next run of quads whose segments fit the image
+    int q1 = q0 + 1;
+    {
+      int lo = q0 + 1, hi = nquads;   // largest q1 with qoff[q1] - qoff[q0] <= ATD_STAGE_ENT
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (qoff_s[mid] - qoff_s[q0] <= (uint32_t)ATD_STAGE_ENT) lo = mid; else hi = mid - 1;
+      }
+      q1 = lo;
     }
-    const int64_t row = perm ? (int64_t)perm[row0 + slot] : (int64_t)row0 + slot;
-    psum[(int64_t)t * n + row] = a;
-    psq[(int64_t)t * n + row] = b;
+    const uint32_t o0 = qoff_s[q0], size = qoff_s[q1] - o0;
+    for (uint32_t i = threadIdx.x; i < size; i += ATD_THREADS) stage[i] = Ent{0u, 0.f};
+    __syncthreads();
+    auto place = [&](uint32_t slot, uint32_t i, uint32_t rank, uint32_t vbits) {
+      const int q = (int)(slot >> 2);
+      if (q < q0 || q >= q1) return;
+      Ent x;
+      x.off = i * (uint32_t)ldp_bytes;
+      x.val = __uint_as_float(vbits);
+      stage[qoff_s[q] - o0 + rank * 4u + (slot & 3u)] = x;
+    };
+#pragma unroll
+    for (int u = 0; u < HOLD; ++u)
+      if (kv[u].x != 0xffffffffu) place((kv[u].x >> 9) & 1023u, kv[u].x & 511u, kv[u].x >> 19, kv[u].y);
+    for (int64_t e = b0 + threadIdx.x + (int64_t)HOLD * ATD_THREADS; e < b1; e += ATD_THREADS) {
+      const uint2 x = bucket[e];
+      const uint32_t slot = x.x >> 9, i = x.x & 511u;
+      const int q = (int)(slot >> 2);
+      if (q >= q0 && q < q1) place(slot, i, rank_of(slot, i), x.y);
+    }
+    __syncthreads();
+    // (segments are multiples of 8 entries: 16-byte pieces)
+    {
+      const uint4* src4 = reinterpret_cast<const uint4*>(stage);
+      uint4* dst4 = reinterpret_cast<uint4*>(dst + o0);
+      for (uint32_t i = threadIdx.x; i < size / 2; i += ATD_THREADS) dst4[i] = src4[i];
+    }
+    const int slot = 4 * q0 + (int)threadIdx.x;
+    if (psum && slot < 4 * q1 && slot < nrows) {
+      int len = 0;
+#pragma unroll
+      for (int w = 0; w < ATD_MASK_WORDS; ++w) len += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
+      const uint32_t o = qoff_s[slot >> 2] - o0 + (uint32_t)(slot & 3);
+      double a = 0, b = 0;
+      for (int k = 0; k < len; ++k) {
+        const double v = (double)stage[o + 4u * k].val;
+        a += v;
+        b += v * v;
+      }
+      const int64_t row = perm ? (int64_t)perm[row0 + slot] : (int64_t)row0 + slot;
+      psum[(int64_t)t * n + row] = a;
+      psq[(int64_t)t * n + row] = b;
+    }
+    __syncthreads();
+    q0 = q1;
   }
 }
 

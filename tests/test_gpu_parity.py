@@ -975,6 +975,44 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(30000, 2500), (700, 5000), (2500, 70), (100000, 300)])
+def test_bucket_route_to_the_transposed_format_on_skewed_columns(monkeypatch, shape):
+    """A^T's format straight from A (per-chunk buckets) against the transposition route on matrices whose columns differ
+    in density by two orders of magnitude (A^T's rows get sorted by length: blocks cut by entry count, rows permuted),
+    tall, wide and narrow: same model to rounding, and the oracle's"""
+    m, n = shape
+    k, p, q = 6, 6, 2
+    rng = np.random.default_rng(m + n)
+    dens_col = np.clip(rng.lognormal(np.log(0.03), 1.2, n), 2e-4, 0.6)
+    cols = [np.flatnonzero(rng.random(m) < d) for d in dens_col]
+    rows = np.concatenate(cols)
+    cidx = np.concatenate([np.full(len(c), j) for j, c in enumerate(cols)])
+    vals = rng.standard_normal(len(rows)).astype(np.float32) + 1.5
+    A = sp.csr_matrix((vals, (rows, cidx)), shape=(m, n))
+    A.sort_indices()
+    om = synth.gaussian_panel(n, k + p, 9).numpy()
+    dev = sapca.DeviceCsr(torch.as_tensor(A.indptr.astype(np.int64), device="cuda"), torch.as_tensor(A.indices.astype(np.int32), device="cuda"),
+                          torch.as_tensor(A.data, device="cuda"), (m, n))
+    out = []
+    for sort_route in (False, True):
+        if sort_route:
+            monkeypatch.setenv("SAPCA_AT_SORT", "1")
+        else:
+            monkeypatch.delenv("SAPCA_AT_SORT", raising=False)
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(dev).cpu().numpy()
+        out.append((pca.singular_values_(np.float64), pca.mean_(np.float64), pca.explained_variance_ratio(np.float64), t))
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-5)
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(out[0][3], out[1][3], atol=2e-4 * np.abs(out[1][3]).max())
+    A64 = A.astype(np.float64)
+    want = O.fit(A64.indptr.astype(np.int64), A64.indices.astype(np.int64), A64.data, m, n, n_components=k, n_oversamples=p,
+                 n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(out[0][0], want.singular_values, rtol=2e-4)
+    np.testing.assert_allclose(out[0][1], want.mean, atol=1e-6)
+
+
 def test_tile_major_builder_with_and_without_its_lds_table(monkeypatch):
     """A^T's format: the row-segment bounds staged in LDS (few tiles) or read from global memory one tile ahead
     (many tiles, C4/C5) -- the same bytes, hence bit-identical fits"""

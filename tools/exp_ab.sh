@@ -5,5 +5,5 @@ NEW=$GRAFT_REPO_ROOT/single-algebra_amd/lib/exp/libsapca_new.so
 for i in 1 2; do
 run SAPCA_LIB_PATH=$OLD
 run SAPCA_LIB_PATH=$NEW
-run SAPCA_LIB_PATH=$NEW SAPCA_AT_SORT=1
+
 done
