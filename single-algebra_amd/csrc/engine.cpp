@@ -258,7 +258,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   }
 
   // R1/R2 (csr.rs:259-312, 558-608) as row sums of A^T, plus the per-column stored-entry count.
-  std::vector<double> sums((size_t)2 * n + 1, 0.0);
+  double* sums = static_cast<double*>(h.stats_host.ensure(((size_t)2 * n + 1) * sizeof(double)));
   auto column_statistics = [&](bool uploaded) {
     Scope sc(h, C_STATS);
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
@@ -277,28 +277,24 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       if (!at_seg_ready) k::row_sums(At, d_stats, d_stats + n, s);
       k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
     }
-    const double m_local = (double)m;
-    SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &m_local, sizeof(double), hipMemcpyHostToDevice, s));
+    h.m_local = (double)m;   // (a member: the copy may still be reading it when this function has returned)
+    SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &h.m_local, sizeof(double), hipMemcpyHostToDevice, s));
     if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s); }
-    SAPCA_HIP(hipMemcpyAsync(sums.data(), d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipMemcpyAsync(&sums[(size_t)2 * n], d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipStreamSynchronize(s));
+    SAPCA_HIP(hipMemcpyAsync(sums, d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(sums + 2 * n, d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
   };
   column_statistics(from_upload);
-  h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
-  const double mg = (double)h.m_global;
-
-  // R3: mean and total variance (sparse/mod.rs:106-131; masked :273-311, over cols_to_use only)
-  h.prep_mean.assign((size_t)n, 0.0);
-  h.prep_total_var = 0;
-  if (h.opt.center) {
-    for (int64_t j = 0; j < n; ++j) h.prep_mean[(size_t)j] = (double)(T)(sums[(size_t)j] / mg);
-    auto var_of = [&](int64_t j) {
-      const double mean = sums[(size_t)j] / mg;
-      return (sums[(size_t)n + j] - mean * sums[(size_t)j]) / (mg - 1.0);
-    };
-    if (masked) for (uint64_t j : h.cols_to_use) h.prep_total_var += var_of((int64_t)j);
-    else for (int64_t j = 0; j < n; ++j) h.prep_total_var += var_of(j);
+  h.stats_cols = n;
+  if (h.comm.active()) {   // the global row count is the sum over the ranks: needed on the host now
+    SAPCA_HIP(hipStreamSynchronize(s));
+    h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
+    h.stats_pending = false;
+    finish_statistics(h);
+  } else {
+    // one rank: the count is m; the sums reach the host by the time fit() ends (the sweeps centre with means computed on
+    // the device), so nothing waits here
+    h.m_global = (uint64_t)m;
+    h.stats_pending = true;
   }
 
   // operator seen by the SVD engines: MaskedCSRMatrix::new (sparse_masked/mod.rs:313)
@@ -383,6 +379,27 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   h.prep_key.ptr = A.ptr; h.prep_key.idx = A.idx; h.prep_key.val = A.val;
   h.prep_key.m = (uint64_t)m; h.prep_key.n = (uint64_t)n; h.prep_key.nnz = (uint64_t)nnz;
   h.prep_key.mask_version = h.mask_version; h.prep_key.dtype = kDtype; h.prep_key.valid = true;
+}
+
+// R3: mean and total variance (sparse/mod.rs:106-131; masked :273-311, over cols_to_use only) from the column sums on the host
+template <typename T>
+void Engine<T>::finish_statistics(H& h) {
+  const int64_t n = h.stats_cols;
+  const double* sums = static_cast<const double*>(h.stats_host.p);
+  const double mg = (double)h.m_global;
+  const bool masked = h.has_mask_maps;
+  h.prep_mean.assign((size_t)n, 0.0);
+  h.prep_total_var = 0;
+  if (h.opt.center) {
+    for (int64_t j = 0; j < n; ++j) h.prep_mean[(size_t)j] = (double)(T)(sums[(size_t)j] / mg);
+    auto var_of = [&](int64_t j) {
+      const double mean = sums[(size_t)j] / mg;
+      return (sums[(size_t)n + j] - mean * sums[(size_t)j]) / (mg - 1.0);
+    };
+    if (masked) for (uint64_t j : h.cols_to_use) h.prep_total_var += var_of((int64_t)j);
+    else for (int64_t j = 0; j < n; ++j) h.prep_total_var += var_of(j);
+  }
+  h.stats_pending = false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -609,14 +626,11 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
 
   // column means of the features the SVD sees, in T (the centring vector of the sweeps and of transform)
   {
-    std::vector<T> mu((size_t)n_used);
-    for (int64_t j = 0; j < n_used; ++j) {
-      const int64_t src = h.has_mask_maps ? (int64_t)h.cols_to_use[(size_t)j] : j;
-      mu[(size_t)j] = (T)h.prep_mean[(size_t)src];
-    }
     T* d_mu = h.mean_used_dev.as<T>((size_t)n_used);
-    SAPCA_HIP(hipMemcpyAsync(d_mu, mu.data(), mu.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    SAPCA_HIP(hipStreamSynchronize(s));
+    if (h.opt.center)
+      k::mean_from_sums(h.stats.ptr<double>(), (double)h.m_global, h.has_mask_maps ? h.sel_rows_dev.ptr<int32_t>() : nullptr, n_used, d_mu, s);
+    else
+      SAPCA_HIP(hipMemsetAsync(d_mu, 0, (size_t)n_used * sizeof(T), s));
   }
 
   if (h.opt.method == SAPCA_RANDOM) fit_randomized(h);
@@ -629,6 +643,10 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
   h.dtype = kDtype;
   // sparse/mod.rs:106-117: mean_ = col_sums / n when centring, zeros otherwise (the reference
   // allocates zeros(n_samples) there -- a length bug that is never read; n_cols zeros here).
+  if (h.stats_pending) {   // (the copy was queued in prepare(); every path through the SVD engines has synchronised since)
+    SAPCA_HIP(hipStreamSynchronize(s));
+    finish_statistics(h);
+  }
   h.mean = h.prep_mean;
   const double nm1 = (double)(h.m_fit - 1);
   h.expl_var.resize(h.k);

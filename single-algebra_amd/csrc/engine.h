@@ -51,6 +51,12 @@ struct sapca_handle_s {
   uint64_t m_global = 0;
   std::vector<double> prep_mean;  // column means of the prepared matrix (n)
   double prep_total_var = 0;
+  // the column sums on the host (sum | sumsq | row count), copied asynchronously: single-rank fits read them at the end
+  // of fit() instead of stalling the stream between the preparation and the first sweep
+  sapca::PinnedBuf stats_host;
+  bool stats_pending = false;
+  int64_t stats_cols = 0;
+  double m_local = 0;
 
   // device buffers (grow-only)
   sapca::DevBuf in_ptr, in_idx, in_val, up64, up64i, out_tmp;    // host-entry uploads
@@ -93,6 +99,7 @@ struct Engine {
   using H = sapca_handle_s;
   static constexpr int kDtype = sizeof(T) == 8 ? 1 : 0;
   static void prepare(H& h, const CsrView<T>& A);
+  static void finish_statistics(H& h);   // host side of R3 from stats_host (mean, total variance)
   static void fit(H& h, const CsrView<T>& A);
   static void transform(H& h, const CsrView<T>& A, T* d_out);
   static void fit_randomized(H& h);

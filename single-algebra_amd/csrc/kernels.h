@@ -43,6 +43,9 @@ template <typename T>
 void exact_colstats_add(const int64_t* ptr, const int32_t* idx, const T* val, int64_t r_lo, int64_t r_hi, int64_t e_lo, int64_t e_hi,
                         int64_t n, void* work, hipStream_t s);
 template <typename T> void exact_colstats_finish(void* work, int64_t n, double* out, int* nonfinite_host, hipStream_t s);
+// mu[j] = T(sum[sel ? sel[j] : j] / count): the column means the sweeps centre with, from the device-side column sums
+template <typename T>
+void mean_from_sums(const double* sum, double count, const int32_t* sel, int64_t n_used, T* mu, hipStream_t s);
 // out[r] = ptr[r+1] - ptr[r] as f64 (column counts when applied to A^T's row offsets)
 void row_lengths_f64(const int64_t* ptr, int64_t rows, double* out, hipStream_t s);
 // out[j] = number of stored entries with column j (integer atomics; transform of a matrix that

@@ -503,6 +503,24 @@ void subtract_column_mean(const CsrView<T>& A, const T* mu_by_col, T* vals_out, 
   SAPCA_HIP(hipGetLastError());
 }
 
+
+namespace {
+template <typename T>
+__global__ void mean_from_sums_kernel(const double* __restrict__ sum, double count, const int32_t* __restrict__ sel, int64_t n_used,
+                                      T* __restrict__ mu) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_used) mu[j] = (T)(sum[sel ? (int64_t)sel[j] : j] / count);
+}
+}  // namespace
+
+template <typename T>
+void mean_from_sums(const double* sum, double count, const int32_t* sel, int64_t n_used, T* mu, hipStream_t s) {
+  if (n_used <= 0) return;
+  hipLaunchKernelGGL((mean_from_sums_kernel<T>), dim3((unsigned)((n_used + 255) / 256)), dim3(256), 0, s, sum, count, sel, n_used, mu);
+  SAPCA_HIP(hipGetLastError());
+}
+template void mean_from_sums<float>(const double*, double, const int32_t*, int64_t, float*, hipStream_t);
+template void mean_from_sums<double>(const double*, double, const int32_t*, int64_t, double*, hipStream_t);
 void row_lengths_f64(const int64_t* ptr, int64_t rows, double* out, hipStream_t s) {
   if (rows == 0) return;
   hipLaunchKernelGGL(ptr_diff_kernel, dim3(grid_for(rows, 256, 1 << 30)), dim3(256), 0, s, ptr, rows, out);

@@ -1840,6 +1840,17 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
   }
   E* d_ent = reinterpret_cast<E*>(buf.ent.ensure((size_t)(total + ENT_SLACK) * sizeof(E)));
+  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows; op.max_chunk = max_chunk;
+  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
+  op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
+  if constexpr (f32) {
+    // the DPP-fed sweep's tables depend on the counts only: queued ahead of the fill (a small kernel that would otherwise wait
+    // behind the other stream's fill for a free CU)
+    op.valid = true;   // (dq_build_tables looks at it)
+    const bool dq_ok = dq_build_tables(op, buf, s);
+    op.valid = false;
+    if (!dq_ok && (block_rows > 512 || max_chunk > stage_cap)) return false;   // only the DPP-fed sweep reads such operators: the caller stays on the row kernel
+  }
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
   // f64 entries are 16 bytes: the LDS image holds QF_CAP_MIN of them (64 KiB), two workgroups per CU
@@ -1920,17 +1931,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   }
   SAPCA_HIP(hipGetLastError());
-  op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows; op.max_chunk = max_chunk;
-  op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
-  op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   op.valid = true;
-  if constexpr (f32) {
-    const bool dq_ok = dq_build_tables(op, buf, s);
-    if (!dq_ok && (block_rows > 512 || max_chunk > stage_cap)) {   // only the DPP-fed sweep reads such operators: the caller stays on the row kernel
-      op.valid = false;
-      return false;
-    }
-  }
   return true;
 }
 }  // namespace
