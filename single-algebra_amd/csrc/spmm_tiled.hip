@@ -1352,16 +1352,18 @@ constexpr int ATD_MAX_COLS = 65536;       // the histogram keeps two 16-bit coun
 constexpr int ATD_THREADS = 1024;
 constexpr int ATD_MASK_WORDS = 10;        // 320 rows of a tile
 
-__global__ void __launch_bounds__(ATD_THREADS)
+constexpr int ATD_HIST_THREADS = 512;   // (a tile per workgroup; eight waves: three or four tiles per CU at once, no second round at C2)
+
+__global__ void __launch_bounds__(ATD_HIST_THREADS)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
                 uint16_t* __restrict__ cnt16) {
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
   const int t = blockIdx.x;
   const int nw = (int)(n2 / 2);
-  for (int i = threadIdx.x; i < nw; i += ATD_THREADS) atd_h32[i] = 0u;
+  for (int i = threadIdx.x; i < nw; i += ATD_HIST_THREADS) atd_h32[i] = 0u;
   __syncthreads();
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  for (int i = wave; i < tc; i += ATD_THREADS / WAVE) {
+  for (int i = wave; i < tc; i += ATD_HIST_THREADS / WAVE) {
     const int64_t r = (int64_t)t + (int64_t)i * nct;
     if (r >= m) break;
     const int64_t e1 = ptr[r + 1];
@@ -1376,7 +1378,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
   }
   __syncthreads();
   uint32_t* out = reinterpret_cast<uint32_t*>(cnt16 + (int64_t)t * n2);
-  for (int i = threadIdx.x; i < nw; i += ATD_THREADS) out[i] = atd_h32[i];
+  for (int i = threadIdx.x; i < nw; i += ATD_HIST_THREADS) out[i] = atd_h32[i];
 }
 
 // len[c] = entries of column c (summed over the tiles); the caller scans it into A^T's row offsets.
@@ -1414,29 +1416,26 @@ __global__ void atd_colmap_kernel(const int32_t* __restrict__ blk, int nrb, cons
   colmap[row] = ((uint32_t)lo << 10) | (uint32_t)(sp - blk[lo]);
 }
 
-// one workgroup per tile of A rows: its entries go to the buckets (block of their column, this tile)
-__global__ void __launch_bounds__(ATD_THREADS)
+// one wave per row of A: its entries go to the buckets (block of their column, tile of the row).  Every contiguous run of
+// lanes bound for the same bucket reserves its places with one atomic on the bucket's cursor; the atomics of a whole row
+// (ten batches of 64 entries) are in flight together.  The order inside a bucket is whatever the atomics make it: the
+// fill ranks entries by their row in the tile, not by their place in the bucket.
+__global__ void __launch_bounds__(256)
 atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val, int64_t m, int nct,
-                   int tc, const uint32_t* __restrict__ colmap, int nrb, const int64_t* __restrict__ bucket_off,
+                   const uint32_t* __restrict__ colmap, const int64_t* __restrict__ bucket_off, uint32_t* __restrict__ cursor,
                    uint2* __restrict__ bucket) {
-  extern __shared__ uint32_t atd_cur[];   // [nrb] entries written to bucket (rb, t) so far, then [nrb] bucket starts (int64)
-  int64_t* atd_base = reinterpret_cast<int64_t*>(atd_cur + ((nrb + 1) & ~1));
-  const int t = blockIdx.x;
-  for (int i = threadIdx.x; i < nrb; i += ATD_THREADS) {
-    atd_cur[i] = 0u;
-    atd_base[i] = bucket_off[(int64_t)i * nct + t];
-  }
-  __syncthreads();
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  for (int i = wave; i < tc; i += ATD_THREADS / WAVE) {
-    const int64_t r = (int64_t)t + (int64_t)i * nct;
-    if (r >= m) break;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  constexpr int UB = 10;
+  for (int64_t r = wave; r < m; r += nwaves) {
+    const int i = (int)(r / nct), t = (int)(r - (int64_t)i * nct);
     const int64_t e1 = ptr[r + 1];
-    constexpr int UB = 10;   // batches of 64 entries in flight: a typical row (a few hundred entries) in one round trip
     for (int64_t eb = ptr[r]; eb < e1; eb += UB * WAVE) {
       int cc[UB];
       uint32_t cmv[UB];
       float vv[UB];
+      int64_t base[UB];
+      int mine[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int64_t e = eb + u * WAVE + lane;
@@ -1444,28 +1443,30 @@ atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
         vv[u] = e < e1 ? val[e] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < UB; ++u) cmv[u] = cc[u] >= 0 ? colmap[cc[u]] : 0u;
+      for (int u = 0; u < UB; ++u) cmv[u] = cc[u] >= 0 ? colmap[cc[u]] : 0xffffffffu;
+      // run leaders reserve: nothing below waits for an atomic before all of them are issued
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        if (eb + u * WAVE >= e1) break;
+        const uint32_t rb = cmv[u] >> 10;
+        const uint32_t prev = __shfl_up(rb, 1);
         const bool valid = cc[u] >= 0;
-        const uint32_t cm = cmv[u];
-        const int rb = (int)(cm >> 10);
-        const uint32_t key = ((cm & 1023u) << 9) | (uint32_t)i;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {   // one LDS atomic per run of lanes bound for the same bucket (columns ascend along the row: a few runs)
-          const int lead = __builtin_ctzll(todo);
-          const int rb0 = __shfl(rb, lead);
-          const unsigned long long mine = __ballot(valid && rb == rb0);
-          uint32_t base = 0u;
-          if (lane == lead) base = atomicAdd(&atd_cur[rb0], (uint32_t)__builtin_popcountll(mine));
-          base = __shfl(base, lead);
-          if (valid && rb == rb0) {
-            const uint32_t pos = base + (uint32_t)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
-            bucket[atd_base[rb0] + pos] = make_uint2(key, __float_as_uint(vv[u]));
-          }
-          todo &= ~mine;
+        const bool leader = valid && (lane == 0 || rb != prev);
+        const unsigned long long leaders = __ballot(leader), valids = __ballot(valid);
+        const unsigned long long upto = leaders & ((2ull << lane) - 1ull);   // leaders at or before this lane
+        mine[u] = upto ? 63 - __builtin_clzll(upto) : 0;
+        base[u] = 0;
+        if (leader) {
+          const unsigned long long above = leaders & ~((2ull << lane) - 1ull);   // leaders past this lane
+          const int next = above ? __builtin_ctzll(above) : __builtin_popcountll(valids);   // (valid lanes are a prefix)
+          const int64_t b = (int64_t)rb * nct + t;
+          base[u] = bucket_off[b] + (int64_t)atomicAdd(&cursor[b], (uint32_t)(next - lane));
         }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int64_t b0 = __shfl(base[u], mine[u]);
+        if (cc[u] >= 0)
+          bucket[b0 + (lane - mine[u])] = make_uint2(((cmv[u] & 1023u) << 9) | (uint32_t)i, __float_as_uint(vv[u]));
       }
     }
   }
@@ -1877,7 +1878,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_raw, d_raw, (int64_t)0, (size_t)nchunks + 1, rocprim::plus<int64_t>(), s));
     const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = round_up((size_t)A.nnz * sizeof(uint2), 256);
     const size_t a_part = direct->stats ? round_up((size_t)nct * op_rows * sizeof(double), 256) : 0;
-    char* base = static_cast<char*>(direct->scratch->ensure(a_col + a_bucket + 2 * a_part + scan_bytes + 256));
+    const size_t a_scan = round_up(scan_bytes + 256, 256);
+    char* base = static_cast<char*>(direct->scratch->ensure(a_col + a_bucket + 2 * a_part + a_scan + (size_t)nchunks * sizeof(uint32_t) + 256));
     uint32_t* d_colmap = reinterpret_cast<uint32_t*>(base);
     uint2* d_bucket = reinterpret_cast<uint2*>(base + a_col);
     double* d_psum = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket) : nullptr;
@@ -1886,8 +1888,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     SAPCA_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, d_raw, d_raw, (int64_t)0, (size_t)nchunks + 1, rocprim::plus<int64_t>(), s));
     hipLaunchKernelGGL(atd_colmap_kernel, dim3((unsigned)((op_rows + 255) / 256)), dim3(256), 0, s, d_blk, (int)nrb, d_perm, op_rows,
                        d_colmap);
-    hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)nct), dim3(ATD_THREADS), (size_t)(nrb + 2) * 12, s, A.ptr, A.idx, A.val,
-                       A.rows, nct, tc, d_colmap, (int)nrb, d_raw, d_bucket);
+    uint32_t* d_cursor = reinterpret_cast<uint32_t*>(base + a_col + a_bucket + 2 * a_part + a_scan);
+    SAPCA_HIP(hipMemsetAsync(d_cursor, 0, (size_t)nchunks * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)std::min<int64_t>((A.rows + 3) / 4, 4096)), dim3(256), 0, s, A.ptr, A.idx, A.val,
+                       A.rows, nct, d_colmap, d_raw, d_cursor, d_bucket);
     hipLaunchKernelGGL(atd_fill_kernel, dim3((unsigned)nchunks), dim3(ATD_THREADS), 0, s, d_bucket, d_raw, d_blk, d_perm, nct, ldp * 4,
                        d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent, d_psum, d_psq, op_rows);
     if (direct->stats)
@@ -1958,7 +1962,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   uint16_t* cnt16 = buf.seg.as<uint16_t>((size_t)nct * n2);   // (takes the place of the per-row tile index of the other routes)
   static LdsAttrState hist_attr;
   ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), (size_t)n2 * 2, hist_attr);
-  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3(ATD_THREADS), (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
+  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3(ATD_HIST_THREADS), (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
   size_t scan_bytes = 0;
   SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, at_ptr, at_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), s));
