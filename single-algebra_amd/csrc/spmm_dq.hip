@@ -44,14 +44,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 
-// One workgroup per (row block, tile): per wave the entry offset and chunk count of its stream, and the descriptor
-// bytes (4 x row slot of every two-step group; steps past the end -> the trash slot).
-__global__ void __launch_bounds__(DQ_THREADS)
+// One wave per (row block, tile, wave of the sweep): the entry offset and chunk count of that wave's stream, and the
+// descriptor bytes (4 x row slot of every two-step group; steps past the end -> the trash slot).
+__global__ void __launch_bounds__(256)
 dq_desc_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __restrict__ chunk_off,
                const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, int rg, uint8_t* __restrict__ desc,
                uint32_t* __restrict__ info, int* __restrict__ max_nch, int64_t nchunks) {
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  for (int64_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {   // (a chunk is a few hundred bytes of tables: several per workgroup)
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wpb = blockDim.x / WAVE, ntasks = nchunks * DQ_WAVES;
+  for (int64_t task = (int64_t)blockIdx.x * wpb + threadIdx.x / WAVE; task < ntasks; task += (int64_t)gridDim.x * wpb) {
+  const int64_t cidx = task / DQ_WAVES;
+  const int wave = (int)(task % DQ_WAVES);
   const int rb = (int)(cidx / nct), t = (int)(cidx % nct);
   const int nrows = blk_row0[rb + 1] - blk_row0[rb];
   const int nquads = (nrows + 3) / 4;
@@ -183,7 +186,7 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   uint32_t* d_info = buf.dq_info.as<uint32_t>(info_words + 4);
   int* d_max = reinterpret_cast<int*>(d_info + info_words);
   SAPCA_HIP(hipMemsetAsync(d_info + (size_t)nchunks * DQ_WAVES * 2, 0, (64 * 2 + 4) * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(dq_desc_kernel, dim3((unsigned)std::min<int64_t>(nchunks, 2048)), dim3(DQ_THREADS), 0, s, op.blk_row0, op.nct,
+  hipLaunchKernelGGL(dq_desc_kernel, dim3((unsigned)std::min<int64_t>(nchunks * DQ_WAVES / 4 + 1, 8192)), dim3(256), 0, s, op.blk_row0, op.nct,
                      op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps), rg, d_desc, d_info, d_max, nchunks);
   SAPCA_HIP(hipGetLastError());
   // (a wave's stream in one tile may be any length: the sweep reloads its descriptor register every 32 chunks.  The chunk

@@ -406,10 +406,17 @@ tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
     for (int t = lane; t < nct; t += WAVE) hist[t] = 0;
     __builtin_amdgcn_wave_barrier();
     const int64_t e0 = ptr[r], e1 = ptr[r + 1];
-    for (int64_t e = e0 + lane; e < e1; e += WAVE) {
-      int q, t;
-      divmod_small(idx[e], nct, inv_nct, q, t);
-      atomicAdd(&hist[t], 1u);
+    for (int64_t eb = e0 + lane; eb < e1; eb += 8 * WAVE) {   // eight loads in flight per lane
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = eb + u * WAVE < e1 ? idx[eb + u * WAVE] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c[u] >= 0) {
+          int q, t;
+          divmod_small(c[u], nct, inv_nct, q, t);
+          atomicAdd(&hist[t], 1u);
+        }
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t carry = 0;
@@ -431,59 +438,62 @@ tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
   }
 }
 
-// one block per (row block, column tile): steps of every quad (= its longest row segment), entry
+// one block per (row block, column tile), one thread per quad: steps of every quad (= its longest row segment), entry
 // offset of every wave, chunk size
-__global__ void __launch_bounds__(QBLOCK_ROWS)
+__global__ void __launch_bounds__(Q_BLOCK_QUADS)
 quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm,
                   int nct, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
                   int64_t* __restrict__ chunk_size, const uint16_t* __restrict__ cnt16 = nullptr, int64_t cnt_stride = 0,
                   int64_t* __restrict__ raw_size = nullptr) {
-  __shared__ uint32_t scan[QBLOCK_ROWS];
-  __shared__ uint32_t raw_total;
+  __shared__ uint32_t scan[Q_BLOCK_QUADS];
+  __shared__ uint32_t wave_total[Q_BLOCK_QUADS / WAVE], raw_part[Q_BLOCK_QUADS / WAVE];
   const int rb = blockIdx.x / nct, ct = blockIdx.x % nct;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
-  const int lr = threadIdx.x;   // local row; its quad is lr / 4
-  int len = 0;
-  if (lr == 0) raw_total = 0;
-  if (lr < nrows) {
-    const int64_t r = perm ? (int64_t)perm[row0 + lr] : (int64_t)row0 + lr;   // slot -> row (rows sorted by length)
-    // (the bucket builder of A^T counts entries per (tile, row) instead of indexing a transposed CSR)
-    len = cnt16 ? (int)cnt16[(int64_t)ct * cnt_stride + r] : seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
-  }
-  if (raw_size) {
-    int w = len;
+  const int q = threadIdx.x, lane = q & (WAVE - 1);
+  int longest = 0, raw = 0;
 #pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) w += __shfl_xor(w, off);
-    __syncthreads();
-    if ((lr & (WAVE - 1)) == 0 && w) atomicAdd(&raw_total, (uint32_t)w);
+  for (int g = 0; g < 4; ++g) {
+    const int lr = 4 * q + g;
+    if (lr < nrows) {
+      const int64_t r = perm ? (int64_t)perm[row0 + lr] : (int64_t)row0 + lr;   // slot -> row (rows sorted by length)
+      // (the bucket builder of A^T counts entries per (tile, row) instead of indexing a transposed CSR)
+      const int len = cnt16 ? (int)cnt16[(int64_t)ct * cnt_stride + r] : seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
+      longest = max(longest, len);
+      raw += len;
+    }
   }
-  int qmax = max(len, __shfl_xor(len, 1));
-  qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
-  const uint32_t padded = (lr & 3) == 0 ? (uint32_t)qmax * 4u : 0u;
-  if ((lr & 3) == 0) steps[(int64_t)blockIdx.x * Q_BLOCK_QUADS + lr / 4] = (uint16_t)qmax;
-  // inclusive scan of the padded quad sizes over the block: inside each wave by shuffles, the 16 wave totals through LDS
-  __shared__ uint32_t wave_total[QBLOCK_ROWS / WAVE];
+  const int qmax = q_steps(longest);
+  const uint32_t padded = (uint32_t)qmax * 4u;
+  steps[(int64_t)blockIdx.x * Q_BLOCK_QUADS + q] = (uint16_t)qmax;
+  // inclusive scan of the padded quad sizes over the block: inside each wave by shuffles, the wave totals through LDS
   uint32_t inc = padded;
 #pragma unroll
   for (int off = 1; off < WAVE; off <<= 1) {
     const uint32_t y = __shfl_up(inc, off);
-    if ((lr & (WAVE - 1)) >= off) inc += y;
+    if (lane >= off) inc += y;
   }
-  if ((lr & (WAVE - 1)) == WAVE - 1) wave_total[lr / WAVE] = inc;
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) raw += __shfl_xor(raw, off);
+  if (lane == WAVE - 1) wave_total[q / WAVE] = inc;
+  if (lane == 0) raw_part[q / WAVE] = (uint32_t)raw;
   __syncthreads();
-  for (int w = 0; w < lr / WAVE; ++w) inc += wave_total[w];
-  scan[lr] = inc;
+  for (int w = 0; w < q / WAVE; ++w) inc += wave_total[w];
+  scan[q] = inc;
   __syncthreads();
   // [row block][quad][tile]: the builder reads one quad's offsets in all tiles contiguously
-  if ((lr & 3) == 0 && lr / 4 < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + lr / 4) * nct + ct] = scan[lr] - padded;
-  if (lr < QWAVES) {
-    const int first_row = 4 * q_first(lr, nquads);
-    wave_off[(int64_t)blockIdx.x * QWAVES + lr] = first_row > 0 ? scan[first_row - 1] : 0u;
+  if (q < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + ct] = inc - padded;
+  if (q < QWAVES) {
+    const int first_quad = q_first(q, nquads);
+    wave_off[(int64_t)blockIdx.x * QWAVES + q] = first_quad > 0 ? scan[first_quad - 1] : 0u;
   }
-  if (lr == QBLOCK_ROWS - 1) {
-    chunk_size[blockIdx.x] = scan[lr];
-    if (raw_size) raw_size[blockIdx.x] = raw_total;   // (the scan's barriers ordered the atomics before this read)
+  if (q == Q_BLOCK_QUADS - 1) {
+    chunk_size[blockIdx.x] = inc;
+    if (raw_size) {
+      uint32_t total = 0;
+      for (int w = 0; w < Q_BLOCK_QUADS / WAVE; ++w) total += raw_part[w];
+      raw_size[blockIdx.x] = total;
+    }
   }
 }
 
@@ -1422,13 +1432,21 @@ __global__ void atd_colmap_kernel(const int32_t* __restrict__ blk, int nrb, cons
 // fill ranks entries by their row in the tile, not by their place in the bucket.
 __global__ void __launch_bounds__(256)
 atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val, int64_t m, int nct,
-                   const uint32_t* __restrict__ colmap, const int64_t* __restrict__ bucket_off, uint32_t* __restrict__ cursor,
+                   int tc, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ bucket_off, uint32_t* __restrict__ cursor,
                    uint2* __restrict__ bucket) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  // workgroups are dealt to the eight XCDs round-robin: XCD x takes the tiles t = x (mod 8), so the partial lines of a bucket
+  // (all its writers handle rows of one tile) meet in one L2 instead of being written back piecemeal from several
+  const int xcd = blockIdx.x & 7;
+  const int64_t wave = (int64_t)(blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const int64_t nwaves = (int64_t)(gridDim.x >> 3) * (blockDim.x / WAVE);
+  const int tiles_x = (nct - xcd + 7) / 8;                 // tiles of this XCD
+  const int64_t items = (int64_t)tiles_x * tc;             // (tile, row in the tile)
   constexpr int UB = 10;
-  for (int64_t r = wave; r < m; r += nwaves) {
-    const int i = (int)(r / nct), t = (int)(r - (int64_t)i * nct);
+  for (int64_t item = wave; item < items; item += nwaves) {
+    const int i = (int)(item / tiles_x), t = xcd + 8 * (int)(item - (int64_t)i * tiles_x);
+    const int64_t r = (int64_t)t + (int64_t)i * nct;
+    if (r >= m) continue;
     const int64_t e1 = ptr[r + 1];
     for (int64_t eb = ptr[r]; eb < e1; eb += UB * WAVE) {
       int cc[UB];
@@ -1801,10 +1819,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                          maskw, d_rank, reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     } else if (quad && direct) {
       d_raw = buf.rank.as<int64_t>((size_t)nchunks + 1);
-      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(QBLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk, direct->cnt16, direct->n2, d_raw);
     } else if (quad)
-      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(QBLOCK_ROWS), 0, s, d_seg, d_blk, d_perm, nct,
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     else if (slots == 2)
       hipLaunchKernelGGL((tiled_count_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
@@ -1890,8 +1908,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                        d_colmap);
     uint32_t* d_cursor = reinterpret_cast<uint32_t*>(base + a_col + a_bucket + 2 * a_part + a_scan);
     SAPCA_HIP(hipMemsetAsync(d_cursor, 0, (size_t)nchunks * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)std::min<int64_t>((A.rows + 3) / 4, 4096)), dim3(256), 0, s, A.ptr, A.idx, A.val,
-                       A.rows, nct, d_colmap, d_raw, d_cursor, d_bucket);
+    hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)std::min<int64_t>(round_up((A.rows + 3) / 4, 8), 4096)), dim3(256), 0, s, A.ptr,
+                       A.idx, A.val, A.rows, nct, tc, d_colmap, d_raw, d_cursor, d_bucket);
     hipLaunchKernelGGL(atd_fill_kernel, dim3((unsigned)nchunks), dim3(ATD_THREADS), 0, s, d_bucket, d_raw, d_blk, d_perm, nct, ldp * 4,
                        d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent, d_psum, d_psq, op_rows);
     if (direct->stats)
