@@ -142,6 +142,18 @@ struct TiledOp {
 };
 struct TiledBuffers {
   DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens, dq_desc, dq_info;
+  // the DPP-fed sweep's tables are a latency-bound kernel over the counts: it runs on this stream beside the
+  // bandwidth-bound fill (fork / join events on the build's own stream)
+  hipStream_t aux = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+  TiledBuffers() = default;
+  TiledBuffers(const TiledBuffers&) = delete;
+  TiledBuffers& operator=(const TiledBuffers&) = delete;
+  ~TiledBuffers() {
+    if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+    if (aux_fork) (void)hipEventDestroy(aux_fork);
+    if (aux_join) (void)hipEventDestroy(aux_join);
+  }
 };
 
 struct Stream {

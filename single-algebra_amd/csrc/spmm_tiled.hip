@@ -1859,6 +1859,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     if (nsplit > 1) nsplit = std::max(1, nsplit / 2);
   }
   E* d_ent = reinterpret_cast<E*>(buf.ent.ensure((size_t)(total + ENT_SLACK) * sizeof(E)));
+  bool aux_pending = false;
   op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows; op.max_chunk = max_chunk;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
   op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
@@ -1866,9 +1867,21 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     // the DPP-fed sweep's tables depend on the counts only: queued ahead of the fill (a small kernel that would otherwise wait
     // behind the other stream's fill for a free CU)
     op.valid = true;   // (dq_build_tables looks at it)
-    const bool dq_ok = dq_build_tables(op, buf, s);
+    if (!buf.aux) {
+      SAPCA_HIP(hipStreamCreateWithFlags(&buf.aux, hipStreamNonBlocking));
+      SAPCA_HIP(hipEventCreateWithFlags(&buf.aux_fork, hipEventDisableTiming));
+      SAPCA_HIP(hipEventCreateWithFlags(&buf.aux_join, hipEventDisableTiming));
+    }
+    SAPCA_HIP(hipEventRecord(buf.aux_fork, s));              // counts, offsets and the block table are final here
+    SAPCA_HIP(hipStreamWaitEvent(buf.aux, buf.aux_fork, 0));
+    const bool dq_ok = dq_build_tables(op, buf, buf.aux);
+    SAPCA_HIP(hipEventRecord(buf.aux_join, buf.aux));
+    aux_pending = true;
     op.valid = false;
-    if (!dq_ok && (block_rows > 512 || max_chunk > stage_cap)) return false;   // only the DPP-fed sweep reads such operators: the caller stays on the row kernel
+    if (!dq_ok && (block_rows > 512 || max_chunk > stage_cap)) {   // only the DPP-fed sweep reads such operators: the caller stays on the row kernel
+      SAPCA_HIP(hipStreamWaitEvent(s, buf.aux_join, 0));
+      return false;
+    }
   }
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
   // the direct fill over a zeroed buffer
@@ -1878,7 +1891,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                            (double)total <= 0.85 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
-  if ((packed_rows || direct) && !runs_fill) return false;
+  if ((packed_rows || direct) && !runs_fill) {
+    if (aux_pending) SAPCA_HIP(hipStreamWaitEvent(s, buf.aux_join, 0));
+    return false;
+  }
   if (staged_fill || runs_fill || direct) SAPCA_HIP(hipMemsetAsync(d_ent + total, 0, (size_t)ENT_SLACK * sizeof(E), s));
   else SAPCA_HIP(hipMemsetAsync(d_ent, 0, (size_t)(total + ENT_SLACK) * sizeof(E), s));
   size_t lds = (size_t)nct * sizeof(uint32_t);
@@ -1953,6 +1969,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   }
   SAPCA_HIP(hipGetLastError());
+  if (aux_pending) SAPCA_HIP(hipStreamWaitEvent(s, buf.aux_join, 0));
   op.valid = true;
   return true;
 }
