@@ -1350,6 +1350,55 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 }
 
 
+// Exclusive scans of one or two int64 arrays of count + 1 elements (the last input element is ignored; the last output is
+// the total) by ONE workgroup, plus the maximum of the first array: the tables here have 1e4 .. 1e6 elements, and one
+// launch replaces six of the library's (histogram / lookback / scan kernels for each of reduce and scan).
+__global__ void __launch_bounds__(1024)
+small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t count, int64_t* __restrict__ out_max_total) {
+  __shared__ int64_t part[2][1024];
+  __shared__ int64_t wmax[16];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int64_t per = (count + 1023) / 1024, lo = min(count, (int64_t)tid * per), hi = min(count, lo + per);
+  int64_t sa = 0, sb = 0, mx = 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    sa += a[i];
+    mx = max(mx, a[i]);
+    if (b) sb += b[i];
+  }
+  part[0][tid] = sa;
+  part[1][tid] = sb;
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+  if (lane == 0) wmax[tid / WAVE] = mx;
+  __syncthreads();
+  if (tid == 0) {   // 1024 partial sums: a serial pass is a few microseconds
+    int64_t ra = 0, rb = 0, m = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const int64_t x = part[0][i], y = part[1][i];
+      part[0][i] = ra;
+      part[1][i] = rb;
+      ra += x;
+      rb += y;
+    }
+    for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
+    a[count] = ra;
+    if (b) b[count] = rb;
+    if (out_max_total) { out_max_total[0] = m; out_max_total[1] = ra; }
+  }
+  __syncthreads();
+  int64_t ra = part[0][tid], rb = part[1][tid];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t x = a[i];
+    a[i] = ra;
+    ra += x;
+    if (b) {
+      const int64_t y = b[i];
+      b[i] = rb;
+      rb += y;
+    }
+  }
+}
+
 // ---- A^T's format straight from A through per-chunk buckets (no transposed CSR, no sort) -----------------------
 // The transposition route moves every entry five times (pack, two radix passes, statistics, fill).  Here a histogram
 // pass counts the entries of every (tile of A rows, column), which is all the quad counting needs; a scatter pass drops
@@ -1830,20 +1879,12 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     else
       hipLaunchKernelGGL((tiled_count_kernel<8, 4>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
                          d_steps, d_wave_off, d_chunk);
-    SAPCA_HIP(hipMemsetAsync(d_chunk + nchunks, 0, sizeof(int64_t), s));
-    // maximum chunk size (staging capacity check), then exclusive scan of the sizes
-    size_t tmp_bytes = 0, tmp2 = 0;
-    SAPCA_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, d_chunk, d_chunk, (int64_t)0, (size_t)nchunks + 1,
-                                      rocprim::plus<int64_t>(), s));
+    // maximum chunk size (staging capacity check) and the exclusive scans of the chunk sizes (and, on the bucket route, of
+    // the stored-entry counts) in one launch
     int64_t* d_max = buf.misc.as<int64_t>(8);
-    SAPCA_HIP(rocprim::reduce(nullptr, tmp2, d_chunk, d_max, (int64_t)0, (size_t)nchunks, rocprim::maximum<int64_t>(), s));
-    char* tmp = static_cast<char*>(buf.tmp.ensure(std::max(tmp_bytes, tmp2) + 256));
-    SAPCA_HIP(rocprim::reduce(tmp, tmp2, d_chunk, d_max, (int64_t)0, (size_t)nchunks, rocprim::maximum<int64_t>(), s));
-    SAPCA_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, d_chunk, d_chunk, (int64_t)0, (size_t)nchunks + 1,
-                                      rocprim::plus<int64_t>(), s));
+    hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, d_chunk, d_raw, nchunks, d_max);
     int64_t host[2] = {0, 0};
-    SAPCA_HIP(hipMemcpyAsync(&host[0], d_max, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipMemcpyAsync(&host[1], d_chunk + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(host, d_max, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));  // blk goes out of scope; sizes needed on the host
     max_chunk = host[0];
     total = host[1];
@@ -1907,9 +1948,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   if (direct) {
     // bucket offsets, column -> (block, slot), the scatter of A's entries, one workgroup per chunk for the format
     const CsrView<float>& A = *direct->A;
-    SAPCA_HIP(hipMemsetAsync(d_raw + nchunks, 0, sizeof(int64_t), s));
-    size_t scan_bytes = 0;
-    SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_raw, d_raw, (int64_t)0, (size_t)nchunks + 1, rocprim::plus<int64_t>(), s));
+    const size_t scan_bytes = 0;   // (d_raw was scanned together with the chunk sizes)
     const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = round_up((size_t)A.nnz * sizeof(uint2), 256);
     const size_t a_part = direct->stats ? round_up((size_t)nct * op_rows * sizeof(double), 256) : 0;
     const size_t a_scan = round_up(scan_bytes + 256, 256);
@@ -1918,8 +1957,6 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     uint2* d_bucket = reinterpret_cast<uint2*>(base + a_col);
     double* d_psum = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket) : nullptr;
     double* d_psq = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket + a_part) : nullptr;
-    void* scan_tmp = base + a_col + a_bucket + 2 * a_part;
-    SAPCA_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, d_raw, d_raw, (int64_t)0, (size_t)nchunks + 1, rocprim::plus<int64_t>(), s));
     hipLaunchKernelGGL(atd_colmap_kernel, dim3((unsigned)((op_rows + 255) / 256)), dim3(256), 0, s, d_blk, (int)nrb, d_perm, op_rows,
                        d_colmap);
     uint32_t* d_cursor = reinterpret_cast<uint32_t*>(base + a_col + a_bucket + 2 * a_part + a_scan);
@@ -1999,10 +2036,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), (size_t)n2 * 2, hist_attr);
   hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3(ATD_HIST_THREADS), (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
-  size_t scan_bytes = 0;
-  SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, at_ptr, at_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), s));
-  void* tmp = buf.tmp.ensure(scan_bytes + 256);
-  SAPCA_HIP(rocprim::exclusive_scan(tmp, scan_bytes, at_ptr, at_ptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), s));
+  hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, at_ptr, (int64_t*)nullptr, n, (int64_t*)nullptr);
   SAPCA_HIP(hipGetLastError());
   CsrView<float> At;
   At.rows = n; At.cols = m; At.nnz = A.nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr;
