@@ -975,11 +975,12 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [(30000, 2500), (700, 5000), (2500, 70), (100000, 300)])
+@pytest.mark.parametrize("shape", [(30000, 2500), (700, 5000), (2500, 70), (100000, 300), (3000, 70000)])
 def test_bucket_route_to_the_transposed_format_on_skewed_columns(monkeypatch, shape):
     """A^T's format straight from A (per-chunk buckets) against the transposition route on matrices whose columns differ
     in density by two orders of magnitude (A^T's rows get sorted by length: blocks cut by entry count, rows permuted),
-    tall, wide and narrow: same model to rounding, and the oracle's"""
+    tall, wide and narrow, and with more columns than the bucket route takes (65536: the transposition steps in while the
+    helper thread is already building A's format): same model to rounding, and the oracle's"""
     m, n = shape
     k, p, q = 6, 6, 2
     rng = np.random.default_rng(m + n)
