@@ -1014,6 +1014,31 @@ def test_bucket_route_to_the_transposed_format_on_skewed_columns(monkeypatch, sh
     np.testing.assert_allclose(out[0][1], want.mean, atol=1e-6)
 
 
+def test_bucket_route_on_a_half_dense_matrix(monkeypatch):
+    """chunks of 80 000 entries (512 columns x 320 rows at density 0.5): the fill keeps ten entries per thread in registers
+    and takes the rest of its bucket from memory; (row, tile) segments of up to 320 entries.  Against the transposition
+    route and the oracle."""
+    m, n, k, p, q = 4000, 2000, 8, 6, 2
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, 0.5, seed=17, dtype=torch.float32))
+    om = synth.gaussian_panel(n, k + p, 2).numpy()
+    dev = sapca.DeviceCsr(torch.as_tensor(ptr.astype(np.int64), device="cuda"), torch.as_tensor(idx.astype(np.int32), device="cuda"),
+                          torch.as_tensor(val, device="cuda"), (m, n))
+    out = []
+    for sort_route in (False, True):
+        if sort_route:
+            monkeypatch.setenv("SAPCA_AT_SORT", "1")
+        else:
+            monkeypatch.delenv("SAPCA_AT_SORT", raising=False)
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(dev).cpu().numpy()
+        out.append((pca.singular_values_(np.float64), pca.mean_(np.float64), t))
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-5)
+    np.testing.assert_allclose(out[0][2], out[1][2], atol=2e-4 * np.abs(out[1][2]).max())
+    want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(out[0][0], want.singular_values, rtol=2e-4)
+
+
 def test_tile_major_builder_with_and_without_its_lds_table(monkeypatch):
     """A^T's format: the row-segment bounds staged in LDS (few tiles) or read from global memory one tile ahead
     (many tiles, C4/C5) -- the same bytes, hence bit-identical fits"""
