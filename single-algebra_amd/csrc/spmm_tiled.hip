@@ -1355,9 +1355,8 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 // launch replaces six of the library's (histogram / lookback / scan kernels for each of reduce and scan).
 __global__ void __launch_bounds__(1024)
 small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t count, int64_t* __restrict__ out_max_total) {
-  __shared__ int64_t part[2][1024];
-  __shared__ int64_t wmax[16];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  __shared__ int64_t wsum[2][16], wmax[16];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int64_t per = (count + 1023) / 1024, lo = min(count, (int64_t)tid * per), hi = min(count, lo + per);
   int64_t sa = 0, sb = 0, mx = 0;
   for (int64_t i = lo; i < hi; ++i) {
@@ -1365,28 +1364,30 @@ small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t coun
     mx = max(mx, a[i]);
     if (b) sb += b[i];
   }
-  part[0][tid] = sa;
-  part[1][tid] = sb;
+  // exclusive scan of the 1024 per-thread sums: inside a wave by shuffles, across the 16 waves through LDS
+  int64_t ia = sa, ib = sb;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const int64_t ya = __shfl_up(ia, off), yb = __shfl_up(ib, off);
+    if (lane >= off) { ia += ya; ib += yb; }
+  }
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-  if (lane == 0) wmax[tid / WAVE] = mx;
+  if (lane == WAVE - 1) { wsum[0][wave] = ia; wsum[1][wave] = ib; }
+  if (lane == 0) wmax[wave] = mx;
   __syncthreads();
-  if (tid == 0) {   // 1024 partial sums: a serial pass is a few microseconds
-    int64_t ra = 0, rb = 0, m = 0;
-    for (int i = 0; i < 1024; ++i) {
-      const int64_t x = part[0][i], y = part[1][i];
-      part[0][i] = ra;
-      part[1][i] = rb;
-      ra += x;
-      rb += y;
-    }
-    for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
-    a[count] = ra;
-    if (b) b[count] = rb;
-    if (out_max_total) { out_max_total[0] = m; out_max_total[1] = ra; }
+  int64_t ra = ia - sa, rb = ib - sb, ta = 0, tb = 0, m = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) { ra += wsum[0][w]; rb += wsum[1][w]; }
+    ta += wsum[0][w];
+    tb += wsum[1][w];
+    m = max(m, wmax[w]);
   }
-  __syncthreads();
-  int64_t ra = part[0][tid], rb = part[1][tid];
+  if (tid == 0) {
+    a[count] = ta;
+    if (b) b[count] = tb;
+    if (out_max_total) { out_max_total[0] = m; out_max_total[1] = ta; }
+  }
   for (int64_t i = lo; i < hi; ++i) {
     const int64_t x = a[i];
     a[i] = ra;
