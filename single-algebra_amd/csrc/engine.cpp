@@ -759,13 +759,8 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
         }
       }
       if (!done) {
-        CsrView<T> As = Au;
-        if (center) {
-          T* sv = h.shifted_val.as<T>((size_t)std::max<int64_t>(Au.nnz, 1));
-          k::subtract_column_mean(Au, mu, sv, s);
-          As.val = sv;
-        }
-        k::spmm(As, center ? nullptr : top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
+        if (center) k::spmm_rows_shifted(Au, W, ldk, d_out, k, k, mu, s);   // (the row kernel subtracts mu_j entry by entry)
+        else k::spmm(Au, top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
       }
     } else {
       // opt-in: the mathematically centred projection (A - 1 mu^T) V^T

@@ -28,9 +28,6 @@ void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, 
 template <typename T>
 void select_rows(const CsrView<T>& At, const int32_t* rows, int64_t n_sel, int64_t* new_ptr, int32_t* new_idx,
                  T* new_val, int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s);
-// vals_out[e] = vals[e] - mu_full[cols_to_use[idx[e]]]   (quirk Q3 operand)
-template <typename T>
-void subtract_column_mean(const CsrView<T>& A, const T* mu_by_col, T* vals_out, hipStream_t s);
 // Exact, order-independent column statistics of a CSR whose entries land chunk by chunk (upstats.hip).  `work` holds the
 // long accumulators.  scan_values (once all values are on the device) fixes the limb window kept in LDS; add takes the
 // entries [e_lo, e_hi) of rows [r_lo, r_hi); finish writes out[0..n) = sum, out[n..2n) = sum of squares, out[2n..3n) =
@@ -74,6 +71,10 @@ void row_stats(const CsrView<T>& A, double* sum, double* sumsq, T* minv, T* maxv
 template <typename T>
 void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, int ldy, int ncols,
           const T* cvec, int variant, DevBuf& scratch, hipStream_t s);
+
+// Y[r][j] = sum over the stored entries of row r of (value - shift[column]) X[column][j]   (quirk Q3 through the row kernel)
+template <typename T>
+void spmm_rows_shifted(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, int ncols, const T* shift, hipStream_t s);
 
 // ---- spmm_tiled.hip ---------------------------------------------------------------------
 // Builds the tile-major format of an f32 operator for panels of leading dimension ldp (64/128).

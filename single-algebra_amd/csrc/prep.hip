@@ -263,13 +263,6 @@ __global__ void copy_selected_kernel(const int64_t* __restrict__ ptr, const int3
   }
 }
 
-template <typename T>
-__global__ void subtract_column_mean_kernel(const int32_t* __restrict__ idx, const T* __restrict__ val,
-                                            int64_t count, const T* __restrict__ mu, T* __restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < count; i += stride) out[i] = val[i] - mu[idx[i]];
-}
 
 // seg[r][t] = number of entries of row r with col < t*tile_cols (t = 0..n_tiles): one lane
 // per (row, boundary) binary search; 64 boundaries of a row share a wave.
@@ -495,13 +488,6 @@ void select_rows(const CsrView<T>& At, const int32_t* rows, int64_t n_sel, int64
   SAPCA_HIP(hipStreamSynchronize(s));
 }
 
-template <typename T>
-void subtract_column_mean(const CsrView<T>& A, const T* mu_by_col, T* vals_out, hipStream_t s) {
-  if (A.nnz == 0) return;
-  hipLaunchKernelGGL((subtract_column_mean_kernel<T>), dim3(grid_for(A.nnz, 256, 8192)), dim3(256), 0, s, A.idx, A.val,
-                     A.nnz, mu_by_col, vals_out);
-  SAPCA_HIP(hipGetLastError());
-}
 
 
 namespace {
@@ -552,7 +538,6 @@ void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* 
                                    hipStream_t);                                                                    \
   template void select_rows<T>(const CsrView<T>&, const int32_t*, int64_t, int64_t*, int32_t*, T*, int64_t*,        \
                                DevBuf&, hipStream_t);                                                               \
-  template void subtract_column_mean<T>(const CsrView<T>&, const T*, T*, hipStream_t);                              \
   template void build_tile_index<T>(const CsrView<T>&, int, int, int32_t*, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)

@@ -54,11 +54,13 @@ template <> __device__ inline void add_vec<double>(double2& a, const double2& b)
 // ---------------------------------------------------------------------------------------
 // Variant 1: one wave per row, panel rows gathered straight from L2 / Infinity Cache.
 // ---------------------------------------------------------------------------------------
-template <typename T, int LPR>
+// SHIFT: every stored value enters as (value - shift[column]) -- quirk Q3, the masked projection's centring at stored
+// entries only (sparse_masked/mod.rs:488-529) -- instead of a pass that writes the shifted values out first
+template <typename T, int LPR, bool SHIFT = false>
 __global__ void __launch_bounds__(256)
 spmm_rowgather_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val,
                       int64_t rows, const T* __restrict__ X, int ldx, T* __restrict__ Y, int ldy, int ncols,
-                      const T* __restrict__ cvec, int vec_store) {
+                      const T* __restrict__ cvec, int vec_store, const T* __restrict__ shift = nullptr) {
   using V = typename Vec<T>::type;
   constexpr int VEC = Vec<T>::N;
   constexpr int SLOTS = WAVE / LPR;
@@ -78,7 +80,8 @@ spmm_rowgather_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
       int64_t e = e0 + slot;
       for (; e + 3 * SLOTS < e1; e += 4 * SLOTS) {
         const int32_t ca = idx[e], cb = idx[e + SLOTS], cc = idx[e + 2 * SLOTS], cd = idx[e + 3 * SLOTS];
-        const T va = val[e], vb = val[e + SLOTS], vc = val[e + 2 * SLOTS], vd = val[e + 3 * SLOTS];
+        T va = val[e], vb = val[e + SLOTS], vc = val[e + 2 * SLOTS], vd = val[e + 3 * SLOTS];
+        if constexpr (SHIFT) { va -= shift[ca]; vb -= shift[cb]; vc -= shift[cc]; vd -= shift[cd]; }
         const V xa = *reinterpret_cast<const V*>(xq + (int64_t)ca * ldx);
         const V xb = *reinterpret_cast<const V*>(xq + (int64_t)cb * ldx);
         const V xc = *reinterpret_cast<const V*>(xq + (int64_t)cc * ldx);
@@ -90,7 +93,8 @@ spmm_rowgather_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
       }
       for (; e < e1; e += SLOTS) {
         const int32_t ca = idx[e];
-        const T va = val[e];
+        T va = val[e];
+        if constexpr (SHIFT) va -= shift[ca];
         const V xa = *reinterpret_cast<const V*>(xq + (int64_t)ca * ldx);
         fma_vec<T>(acc0, va, xa);
       }
@@ -118,15 +122,20 @@ spmm_rowgather_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
 }
 
 template <typename T, int LPR>
-void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, int ncols, const T* cvec, hipStream_t s) {
+void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, int ncols, const T* cvec, hipStream_t s,
+                      const T* shift = nullptr) {
   constexpr int VEC = Vec<T>::N;
   const int vec_store = (ldy % VEC == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
                         (cvec == nullptr || (reinterpret_cast<uintptr_t>(cvec) & 15) == 0);
   int64_t blocks = (A.rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((spmm_rowgather_kernel<T, LPR>), dim3((unsigned)blocks), dim3(256), 0, s, A.ptr, A.idx, A.val,
-                     A.rows, X, ldx, Y, ldy, ncols, cvec, vec_store);
+  if (shift)
+    hipLaunchKernelGGL((spmm_rowgather_kernel<T, LPR, true>), dim3((unsigned)blocks), dim3(256), 0, s, A.ptr, A.idx, A.val,
+                       A.rows, X, ldx, Y, ldy, ncols, cvec, vec_store, shift);
+  else
+    hipLaunchKernelGGL((spmm_rowgather_kernel<T, LPR>), dim3((unsigned)blocks), dim3(256), 0, s, A.ptr, A.idx, A.val,
+                       A.rows, X, ldx, Y, ldy, ncols, cvec, vec_store, shift);
 }
 
 }  // namespace
@@ -163,6 +172,23 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
   else launch_rowgather<T, 32>(A, X, ldx, Y, ldy, ncols, cvec, s);
   SAPCA_HIP(hipGetLastError());
 }
+
+// Y[r][j] = sum over the stored entries of row r of (value - shift[column]) X[column][j]: the row kernel with the shift folded in
+template <typename T>
+void spmm_rows_shifted(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, int ncols, const T* shift, hipStream_t s) {
+  constexpr int VEC = Vec<T>::N;
+  SAPCA_CHECK(ldx % VEC == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ncols <= ldx && ncols <= ldy && shift != nullptr, SAPCA_ERR_ARG,
+              "spmm_rows_shifted: bad panel or shift");
+  if (A.rows == 0) return;
+  const int lanes_needed = (ldx + VEC - 1) / VEC;
+  if (lanes_needed <= 4) launch_rowgather<T, 4>(A, X, ldx, Y, ldy, ncols, (const T*)nullptr, s, shift);
+  else if (lanes_needed <= 8) launch_rowgather<T, 8>(A, X, ldx, Y, ldy, ncols, (const T*)nullptr, s, shift);
+  else if (lanes_needed <= 16) launch_rowgather<T, 16>(A, X, ldx, Y, ldy, ncols, (const T*)nullptr, s, shift);
+  else launch_rowgather<T, 32>(A, X, ldx, Y, ldy, ncols, (const T*)nullptr, s, shift);
+  SAPCA_HIP(hipGetLastError());
+}
+template void spmm_rows_shifted<float>(const CsrView<float>&, const float*, int, float*, int, int, const float*, hipStream_t);
+template void spmm_rows_shifted<double>(const CsrView<double>&, const double*, int, double*, int, int, const double*, hipStream_t);
 
 template void spmm<float>(const CsrView<float>&, const TiledOp*, const float*, int, float*, int, int, const float*, int, DevBuf&, hipStream_t);
 template void spmm<double>(const CsrView<double>&, const TiledOp*, const double*, int, double*, int, int, const double*, int, DevBuf&, hipStream_t);
