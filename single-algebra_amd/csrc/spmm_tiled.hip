@@ -482,7 +482,7 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
   scan[q] = inc;
   __syncthreads();
   // [row block][quad][tile]: the builder reads one quad's offsets in all tiles contiguously
-  if (q < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + ct] = inc - padded;
+  if (quad_off && q < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + ct] = inc - padded;   // (the bucket route rebuilds them from `steps`)
   if (q < QWAVES) {
     const int first_quad = q_first(q, nquads);
     wave_off[(int64_t)blockIdx.x * QWAVES + q] = first_quad > 0 ? scan[first_quad - 1] : 0u;
@@ -1553,15 +1553,31 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
   __shared__ uint32_t mask[QBLOCK_ROWS * ATD_MASK_WORDS];
   __shared__ __attribute__((aligned(16))) Ent stage[ATD_STAGE_ENT];
   __shared__ uint32_t qoff_s[Q_BLOCK_QUADS + 1];
+  __shared__ uint32_t wtot[Q_BLOCK_QUADS / WAVE];
   const int64_t chunk = blockIdx.x;
   const int rb = (int)(chunk / nct), t = (int)(chunk % nct);
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
   for (int i = threadIdx.x; i < QBLOCK_ROWS * ATD_MASK_WORDS; i += ATD_THREADS) mask[i] = 0u;
-  const uint32_t chunk_entries = (uint32_t)(chunk_off[chunk + 1] - chunk_off[chunk]);
-  if (threadIdx.x <= Q_BLOCK_QUADS) {
-    const int q = threadIdx.x;
-    qoff_s[q] = q < nquads ? quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + t] : chunk_entries;
+  // entry offsets of the quads inside the chunk: the scan of their step counts (4 entries per step)
+  if (threadIdx.x < Q_BLOCK_QUADS) {
+    const int q = threadIdx.x, lane = q & (WAVE - 1);
+    const uint32_t sz = q < nquads ? 4u * (uint32_t)steps[chunk * Q_BLOCK_QUADS + q] : 0u;
+    uint32_t inc = sz;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const uint32_t y = __shfl_up(inc, off);
+      if (lane >= off) inc += y;
+    }
+    qoff_s[q + 1] = inc;                       // inclusive, within the wave
+    if (lane == WAVE - 1) wtot[q / WAVE] = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < Q_BLOCK_QUADS) {
+    uint32_t add = 0;
+    for (int w = 0; w < (int)threadIdx.x / WAVE; ++w) add += wtot[w];
+    qoff_s[threadIdx.x + 1] += add;
+    if (threadIdx.x == 0) qoff_s[0] = 0u;
   }
   __syncthreads();
   const int64_t b0 = bucket_off[chunk], b1 = bucket_off[chunk + 1];
@@ -1870,7 +1886,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     } else if (quad && direct) {
       d_raw = buf.rank.as<int64_t>((size_t)nchunks + 1);
       hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
-                         reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk, direct->cnt16, direct->n2, d_raw);
+                         reinterpret_cast<uint16_t*>(d_steps), (uint32_t*)nullptr, d_wave_off, d_chunk, direct->cnt16, direct->n2, d_raw);
     } else if (quad)
       hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
