@@ -13,7 +13,9 @@
 //    quad) advance in lockstep, so the format stores a quad's segment step by step, 4 entries per step,
 //    padded with {0, 0.0f} to its longest row.  8 quads per wave, accumulators in VGPRs across all tiles,
 //    no cross-lane reduction.  Builders: histogram/index + count + fill (LDS-staged for A, streaming for
-//    the tile-major rows of A^T, direct scatter as the fallback), or A^T straight from A (tquad_*).
+//    the tile-major rows of A^T, direct scatter as the fallback), or A^T straight from A: through per-chunk
+//    buckets (atd_*, round 2: the default for unmasked f32 fits; no transposed CSR, no sort) or round 1's
+//    tquad_* (short runs of A per chunk).  The production sweep over this format is spmm_dq.hip's.
 //
 //  * "pair" (SAPCA_TILED_FMT=0; first half): contiguous column tiles of 96 KiB; the two half-waves of a
 //    wave take two consecutive entries of ONE row per step (ds_read_b64), accumulators duplicated in the
