@@ -187,10 +187,62 @@ CsrView<T> device_view(uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p, c
   return a;
 }
 
+// dst <- src on a few host threads (a pageable destination at DRAM speed instead of one core's)
+void parallel_copy(void* dst, const void* src, size_t bytes, unsigned nthreads) {
+  if (nthreads <= 1 || bytes < ((size_t)1 << 20)) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes + nthreads - 1) / nthreads + 63) & ~(size_t)63;
+  for (unsigned t = 1; t < nthreads; ++t) {
+    const size_t lo = std::min(bytes, t * per), hi = std::min(bytes, lo + per);
+    if (lo < hi) th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo); });
+  }
+  std::memcpy(dst, src, std::min(bytes, per));
+  for (auto& x : th) x.join();
+}
+
+// Device -> caller's (pageable) host array.  A direct copy to pageable memory runs at about 10 GB/s; results of more than a
+// few MB (the m x k projection) go through the page-locked ring of the upload instead: DMA into one half while a few
+// threads copy the other half out.
 template <typename T>
 void download_out(sapca_handle h, const T* d, T* out, size_t count) {
-  SAPCA_HIP(hipMemcpyAsync(out, d, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
-  SAPCA_HIP(hipStreamSynchronize(h->stream));
+  hipStream_t s = h->stream;
+  const size_t bytes = count * sizeof(T);
+  constexpr size_t kPiece = (size_t)8 << 20;
+  if (bytes < 2 * kPiece) {
+    SAPCA_HIP(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  const unsigned nthreads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  for (int b = 0; b < 2; ++b) {
+    h->up_stage[b].ensure(kPiece);
+    if (!h->up_done[b]) SAPCA_HIP(hipEventCreateWithFlags(&h->up_done[b], hipEventDisableTiming));
+  }
+  const char* src = reinterpret_cast<const char*>(d);
+  char* dst = reinterpret_cast<char*>(out);
+  size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};
+  int b = 0;
+  for (size_t off = 0; off < bytes; off += kPiece, b ^= 1) {
+    if (pending_len[b]) {   // the piece that used this half: drained, copy it out
+      SAPCA_HIP(hipEventSynchronize(h->up_done[b]));
+      parallel_copy(dst + pending_off[b], h->up_stage[b].p, pending_len[b], nthreads);
+    }
+    const size_t len = std::min(kPiece, bytes - off);
+    SAPCA_HIP(hipMemcpyAsync(h->up_stage[b].p, src + off, len, hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipEventRecord(h->up_done[b], s));
+    pending_off[b] = off;
+    pending_len[b] = len;
+  }
+  for (int i = 0; i < 2; ++i, b ^= 1)   // oldest first
+    if (pending_len[b]) {
+      SAPCA_HIP(hipEventSynchronize(h->up_done[b]));
+      parallel_copy(dst + pending_off[b], h->up_stage[b].p, pending_len[b], nthreads);
+      pending_len[b] = 0;
+    }
+  SAPCA_HIP(hipStreamSynchronize(s));
 }
 
 template <typename T>

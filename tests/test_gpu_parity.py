@@ -96,6 +96,22 @@ def test_statistics_gathered_behind_the_upload_are_the_exact_sums(session, dtype
     assert np.isinf(s2[idx[3]]) and np.array_equal(cnt2, cnt)
 
 
+def test_large_projection_comes_back_through_the_pinned_ring():
+    """a projection of more than 16 MB returns to the caller's (pageable) array in 8 MB pieces through the page-locked ring,
+    copied out by a few threads while the next piece's DMA runs: the same numbers as the device-resident call"""
+    m, n, k, p, q = 150000, 300, 40, 8, 1
+    dev = synth.gapped_csr(m, n, 0.05, 10, seed=2, dtype=torch.float32, device="cuda")
+    ptr, idx, val = csr_np(dev)
+    om = synth.gaussian_panel(n, k + p, 4).numpy()
+    host = _builder(k, p, q).build().set_omega(om)
+    t_host = host.fit_transform(mat(ptr, idx, val, m, n))
+    assert t_host.nbytes > 2 * (8 << 20) and t_host.shape == (m, k)
+    res = _builder(k, p, q).build().set_omega(om)
+    t_dev = res.fit_transform(sapca.DeviceCsr(*dev, (m, n))).cpu().numpy()
+    np.testing.assert_allclose(t_host, t_dev, atol=2e-4 * np.abs(t_dev).max())
+    assert np.isfinite(t_host).all() and np.abs(t_host[-1]).max() > 0          # the last piece arrived
+
+
 def test_host_fits_are_bitwise_reproducible_and_match_resident_fits(monkeypatch):
     """the statistics gathered behind the upload do not depend on the order the chunks' atomics land in: two host fits are
     bit-identical; the same matrix fitted from device-resident arrays (row sums of A^T) gives the same model to rounding"""
