@@ -156,6 +156,16 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
                      h.up_stats.m == (uint64_t)m && h.up_stats.n == (uint64_t)n && h.up_stats.nnz == (uint64_t)nnz &&
                      h.up_stats.dtype == kDtype && n > 0 && !h.comm.active();   // (ranks must not differ in their collectives)
 
+  if (from_upload) {
+    // the last chunk's share of those statistics may still be in flight; the accumulators refuse inf/nan (the flag is
+    // final once the side stream has passed up_stats_done): the sums of the transposed matrix take over then
+    SAPCA_HIP(hipEventSynchronize(h.up_stats_done));
+    if (*static_cast<const int*>(h.up_stats.flag.p) != 0) {
+      h.up_stats.valid = false;
+      from_upload = false;
+    }
+  }
+
   // A's side of the preparation runs beside the main stream.  Its pieces synchronise with the host (entry counts come
   // back), so where the main thread has its own synchronising work a helper thread drives them on the side stream:
   //  * masked fits: the column compaction (MaskedCSRMatrix::new, sparse_masked/mod.rs:313), then the compacted matrix's format;
@@ -171,6 +181,25 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   const bool serial = getenv("SAPCA_PREPARE_SERIAL") != nullptr;
   const bool masked_aside = masked && n_used > 0 && !serial;
   const bool try_direct = sizeof(T) == 4 && at_tile_major && !masked && !serial;   // A^T's format without a transposed CSR
+  // Masked fits on the staged sweep take the same bucket route on the COMPACTED matrix (no transposition of the whole
+  // matrix, no row selection of A^T): the compaction then runs here, ahead of both format builds; the sums of the
+  // masked-out columns (mean_ is full width, sparse_masked/mod.rs:279-286) come from transposing only those columns.
+  const bool try_masked_direct = sizeof(T) == 4 && at_tile_major && masked_aside && n_used <= 65536 && getenv("SAPCA_AT_SORT") == nullptr;
+  bool compaction_done = false;
+  int32_t* drop_col = nullptr;
+  T* drop_val = nullptr;
+  if (try_masked_direct) {
+    Scope sc(h, C_PREPARE);
+    int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
+    int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    // (the entries that are not kept leave as (column, value) pairs: their column sums are taken below)
+    drop_col = from_upload ? nullptr : h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    drop_val = from_upload ? nullptr : h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val);
+    h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
+    compaction_done = true;
+  }
   if (masked_aside || try_direct) {
     if (!h.stream2) {
       SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
@@ -180,12 +209,14 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     SAPCA_HIP(hipEventRecord(h.ev_fork, s));   // A (and the index maps) are on the device
     h.tiled_a = TiledOp();
     a_built_aside = true;
-    aside = std::thread([&, n_used, tiled_ldp] {
+    aside = std::thread([&, n_used, tiled_ldp, compaction_done] {
       try {
         SAPCA_HIP(hipSetDevice(h.device));
         SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
         CsrView<T> src = A;
-        if (masked) {
+        if (masked && compaction_done) {
+          src = view(h.a_used);
+        } else if (masked) {
           int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
           int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
           T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
@@ -204,16 +235,6 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     });
   }
 
-  if (from_upload) {
-    // the last chunk's share of those statistics may still be in flight; the accumulators refuse inf/nan (the flag is
-    // final once the side stream has passed up_stats_done): the sums of the transposed matrix take over then
-    SAPCA_HIP(hipEventSynchronize(h.up_stats_done));
-    if (*static_cast<const int*>(h.up_stats.flag.p) != 0) {
-      h.up_stats.valid = false;
-      from_upload = false;
-    }
-  }
-
   // A^T's tile-major format straight from A (spmm_tiled.hip, "bucket route"): no transposed CSR, no sort; the column
   // statistics come out of the same pass.  Outside its limits (more than 65536 columns, ...) the transposition takes over.
   bool at_direct = false;
@@ -228,7 +249,32 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     }
   }
 
-  if (!at_direct) {
+  bool masked_direct = false;
+  if constexpr (sizeof(T) == 4) {
+    if (compaction_done && nnz_used > 0) {
+      Scope sc(h, C_PREPARE);
+      double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+      int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
+      double* d_part = h.scratch2.as<double>((size_t)2 * n_used + 2);   // sums | sums of squares of the kept columns, compact numbering
+      h.tiled_at = TiledOp();
+      masked_direct = k::build_tiled_at_direct(view(h.a_used), tiled_ldp, h.tiled_at, h.tb_at, cat_ptr, from_upload ? nullptr : d_part, h.scratch, s);
+      if (masked_direct) {
+        h.at_used = {n_used, m, nnz_used, cat_ptr, nullptr, nullptr};
+        if (!from_upload) {
+          // sums of every column from the pairs the compaction dropped (zero where a column is kept), then the kept
+          // columns' sums from the bucket route on top; the per-column counts are only read by the unmasked projection
+          SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
+          k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                            h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                            d_stats, d_stats + n, h.scratch, s);
+          k::scatter_pairs(d_part, d_part + n_used, d_sel, n_used, d_stats, d_stats + n, s);
+        }
+        At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = nullptr; At.idx = nullptr; At.val = nullptr;
+      }
+    }
+  }
+
+  if (!at_direct && !masked_direct) {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
     int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
@@ -266,6 +312,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       SAPCA_HIP(hipMemcpyAsync(d_stats, h.up_stats.out.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
     } else if (at_direct) {
       k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);   // (the sums came out of the format build)
+    } else if (masked_direct) {
+      // (sums in place; the per-column counts are only read by the unmasked projection)
     } else {
       if constexpr (sizeof(T) == 4) {
         // packed tile-major rows: the statistics pass also leaves the A^T builder's per-row tile index behind
@@ -299,9 +347,11 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   // operator seen by the SVD engines: MaskedCSRMatrix::new (sparse_masked/mod.rs:313)
   int64_t nnz_used_t = 0;
-  if (masked) {
+  if (masked_direct) {
+    nnz_used_t = nnz_used;   // (a_used and at_used were set on the bucket route)
+  } else if (masked) {
     Scope sc(h, C_PREPARE);
-    if (!masked_aside) {
+    if (!masked_aside && !compaction_done) {
       int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
       int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
       T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
@@ -326,13 +376,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   // tile-major companions for the LDS-staged sweep
   if (!a_built_aside) h.tiled_a = TiledOp();
-  if (!at_direct) h.tiled_at = TiledOp();
+  if (!at_direct && !masked_direct) h.tiled_at = TiledOp();
   if constexpr (sizeof(T) == 4) {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
       if (!a_built_aside) ok_a_aside = k::build_tiled(view(h.a_used), false, tiled_ldp, h.tiled_a, h.tb_a, s);
       if (!from_at) join_aside();   // (this route reads the compacted A)
-      bool ok_at = at_direct || (!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
+      bool ok_at = at_direct || masked_direct || (!from_at && k::build_tiled(view(h.a_used), true, tiled_ldp, h.tiled_at, h.tb_at, s)) ||
                    k::build_tiled(view(h.at_used), false, tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major, at_packed, true, at_seg_ready);
       if (at_packed && !ok_at) {   // someone needs the transposed CSR after all
         k::unpack_transposed(at_packed, nnz, const_cast<int32_t*>(At.idx), reinterpret_cast<float*>(const_cast<T*>(At.val)), s);
@@ -349,11 +399,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       if (!ok_a || !ok_at) {
         h.tiled_a = TiledOp();
         h.tiled_at = TiledOp();
-        if (at_direct) {   // the row kernel reads a transposed CSR, which the bucket route never made
-          int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
-          T* at_val = h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-          k::transpose_csr(A, h.at_ptr.as<int64_t>((size_t)n + 1), at_idx, at_val, h.scratch, s, 0, nullptr);
-          h.at_used = {n, m, nnz, h.at_ptr.p, at_idx, at_val};
+        if (at_direct || masked_direct) {   // the row kernel reads a transposed CSR, which the bucket route never made
+          const CsrView<T> src = view(h.a_used);   // (the compacted matrix on the masked route)
+          int64_t* t_ptr = masked_direct ? h.cat_ptr.as<int64_t>((size_t)n_used + 1) : h.at_ptr.as<int64_t>((size_t)n + 1);
+          int32_t* t_idx = (masked_direct ? h.cat_idx : h.at_idx).template as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+          T* t_val = (masked_direct ? h.cat_val : h.at_val).template as<T>((size_t)std::max<int64_t>(nnz, 1));
+          k::transpose_csr(src, t_ptr, t_idx, t_val, h.scratch, s, 0, nullptr);
+          h.at_used = {src.cols, src.rows, src.nnz, t_ptr, t_idx, t_val};
         }
       }
     }

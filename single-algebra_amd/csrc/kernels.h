@@ -23,7 +23,12 @@ void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s);
 // Mask compaction of A: keep entries with o2m[col] >= 0, renumbered.  Two passes around a scan.
 template <typename T>
 void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
-                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s);
+                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col = nullptr, T* drop_val = nullptr);
+// (drop_col / drop_val, A.nnz each, receive the entries that were NOT kept as (original column, value) pairs, row after row)
+// sum[c], sumsq[c] (c < n) over (column, value) pairs through a stable sort by column; seg (n + 1), keys_out, vals_out: work arrays
+template <typename T>
+void sums_by_column(const int32_t* cols, const T* vals, int64_t count, int64_t n, int64_t* seg, int32_t* keys_out, T* vals_out,
+                    double* sum, double* sumsq, DevBuf& scratch, hipStream_t s);
 // Row selection of A^T: rows listed in `rows` (ascending), column indices untouched.
 template <typename T>
 void select_rows(const CsrView<T>& At, const int32_t* rows, int64_t n_sel, int64_t* new_ptr, int32_t* new_idx,
@@ -40,6 +45,8 @@ template <typename T>
 void exact_colstats_add(const int64_t* ptr, const int32_t* idx, const T* val, int64_t r_lo, int64_t r_hi, int64_t e_lo, int64_t e_hi,
                         int64_t n, void* work, hipStream_t s);
 template <typename T> void exact_colstats_finish(void* work, int64_t n, double* out, int* nonfinite_host, hipStream_t s);
+// out_a[where[j]] = a[j], out_b[where[j]] = b[j]   (column statistics from a compacted numbering back to the full width)
+void scatter_pairs(const double* a, const double* b, const int32_t* where, int64_t count, double* out_a, double* out_b, hipStream_t s);
 // mu[j] = T(sum[sel ? sel[j] : j] / count): the column means the sweeps centre with, from the device-side column sums
 template <typename T>
 void mean_from_sums(const double* sum, double count, const int32_t* sel, int64_t n_used, T* mu, hipStream_t s);

@@ -196,7 +196,13 @@ __global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
   for (int64_t r = wave; r < rows; r += nwaves) {
     int c = 0;
     const int64_t e1 = ptr[r + 1];
-    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) c += o2m[idx[e]] >= 0;
+    for (int64_t eb = ptr[r] + lane; eb < e1; eb += 8 * WAVE) {   // eight loads in flight per lane
+      int col[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) col[u] = eb + u * WAVE < e1 ? idx[eb + u * WAVE] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c += col[u] >= 0 ? (o2m[col[u]] >= 0) : 0;
+    }
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if (lane == 0) cnt[r] = c;
@@ -204,32 +210,50 @@ __global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
   if (blockIdx.x == 0 && threadIdx.x == 0) cnt[rows] = 0;
 }
 
+// kept entries -> (new_idx, new_val) at new_ptr[row]; optionally the dropped ones -> (drop_col = ORIGINAL column, drop_val),
+// row after row (row r's start: the entries before it that were not kept, ptr[r] - new_ptr[r])
 template <typename T>
 __global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                   const T* __restrict__ val, int64_t rows, const int32_t* __restrict__ o2m,
                                   const int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_idx,
-                                  T* __restrict__ new_val) {
+                                  T* __restrict__ new_val, int32_t* __restrict__ drop_col, T* __restrict__ drop_val) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
   for (int64_t r = wave; r < rows; r += nwaves) {
     int64_t out = new_ptr[r];
     const int64_t e0 = ptr[r], e1 = ptr[r + 1];
-    for (int64_t base = e0; base < e1; base += WAVE) {
-      const int64_t e = base + lane;
-      int32_t mi = -1;
-      T v = 0;
-      if (e < e1) {
-        mi = o2m[idx[e]];
-        v = val[e];
+    int64_t dout = e0 - out;
+    for (int64_t base = e0; base < e1; base += 4 * WAVE) {   // four batches of loads in flight
+      int col[4], mi[4];
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t e = base + u * WAVE + lane;
+        col[u] = e < e1 ? idx[e] : -1;
+        v[u] = e < e1 ? val[e] : (T)0;
       }
-      const unsigned long long keep = __ballot(mi >= 0);
-      const int before = __popcll(keep & ((1ull << lane) - 1ull));
-      if (mi >= 0) {
-        new_idx[out + before] = mi;
-        new_val[out + before] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mi[u] = col[u] >= 0 ? o2m[col[u]] : -1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long keep = __ballot(mi[u] >= 0);
+        const int before = __popcll(keep & ((1ull << lane) - 1ull));
+        if (mi[u] >= 0) {
+          new_idx[out + before] = mi[u];
+          new_val[out + before] = v[u];
+        }
+        out += __popcll(keep);
+        if (drop_col) {
+          const unsigned long long drop = __ballot(col[u] >= 0 && mi[u] < 0);
+          if (col[u] >= 0 && mi[u] < 0) {
+            const int64_t o = dout + __popcll(drop & ((1ull << lane) - 1ull));
+            drop_col[o] = col[u];
+            drop_val[o] = v[u];
+          }
+          dout += __popcll(drop);
+        }
       }
-      out += __popcll(keep);
     }
   }
 }
@@ -463,15 +487,43 @@ void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s) {
 
 template <typename T>
 void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
-                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s) {
+                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col, T* drop_val) {
   const int g = grid_for(A.rows * WAVE, 256, 4096);
   hipLaunchKernelGGL((count_kept_kernel<T>), dim3(g), dim3(256), 0, s, A.ptr, A.idx, A.rows, o2m, new_ptr);
   exclusive_scan_i64(new_ptr, A.rows + 1, scratch, 0, s);
   hipLaunchKernelGGL((write_kept_kernel<T>), dim3(g), dim3(256), 0, s, A.ptr, A.idx, A.val, A.rows, o2m, new_ptr,
-                     new_idx, new_val);
+                     new_idx, new_val, drop_col, drop_val);
   SAPCA_HIP(hipGetLastError());
   SAPCA_HIP(hipMemcpyAsync(new_nnz_host, new_ptr + A.rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   SAPCA_HIP(hipStreamSynchronize(s));
+}
+
+// sum[c], sumsq[c] over the (column, value) pairs, c < n: a stable radix sort by column (the pairs keep their row order
+// inside a column: the same summation order as the row sums of a transposed CSR), segment offsets, row sums.
+// seg (n + 1), keys_out / vals_out (count) are work arrays.
+template <typename T>
+void sums_by_column(const int32_t* cols, const T* vals, int64_t count, int64_t n, int64_t* seg, int32_t* keys_out, T* vals_out,
+                    double* sum, double* sumsq, DevBuf& scratch, hipStream_t s) {
+  if (n <= 0) return;
+  if (count <= 0) {
+    SAPCA_HIP(hipMemsetAsync(sum, 0, (size_t)n * sizeof(double), s));
+    SAPCA_HIP(hipMemsetAsync(sumsq, 0, (size_t)n * sizeof(double), s));
+    return;
+  }
+  int bits = 1;
+  while ((1ll << bits) < n) ++bits;
+  size_t sb = 0;
+  SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const T*)nullptr, (T*)nullptr,
+                                      (size_t)count, 0u, (unsigned)bits, s));
+  void* tmp = scratch.ensure(sb + 256);
+  SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, reinterpret_cast<const uint32_t*>(cols), reinterpret_cast<uint32_t*>(keys_out), vals, vals_out,
+                                      (size_t)count, 0u, (unsigned)bits, s));
+  hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(n + 1, 256, 1 << 30)), dim3(256), 0, s,
+                     reinterpret_cast<const uint32_t*>(keys_out), count, n, seg);
+  CsrView<T> Xt;
+  Xt.rows = n; Xt.cols = 0; Xt.nnz = count; Xt.ptr = seg; Xt.idx = keys_out; Xt.val = vals_out;
+  row_sums(Xt, sum, sumsq, s);
+  SAPCA_HIP(hipGetLastError());
 }
 
 template <typename T>
@@ -498,6 +550,23 @@ __global__ void mean_from_sums_kernel(const double* __restrict__ sum, double cou
   if (j < n_used) mu[j] = (T)(sum[sel ? (int64_t)sel[j] : j] / count);
 }
 }  // namespace
+
+namespace {
+__global__ void scatter_pairs_kernel(const double* __restrict__ a, const double* __restrict__ b, const int32_t* __restrict__ where,
+                                     int64_t count, double* __restrict__ out_a, double* __restrict__ out_b) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) {
+    out_a[where[j]] = a[j];
+    out_b[where[j]] = b[j];
+  }
+}
+}  // namespace
+
+void scatter_pairs(const double* a, const double* b, const int32_t* where, int64_t count, double* out_a, double* out_b, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, where, count, out_a, out_b);
+  SAPCA_HIP(hipGetLastError());
+}
 
 template <typename T>
 void mean_from_sums(const double* sum, double count, const int32_t* sel, int64_t n_used, T* mu, hipStream_t s) {
@@ -535,7 +604,9 @@ void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* 
                                  const uint64_t**);                                                                 \
   template void row_sums<T>(const CsrView<T>&, double*, double*, hipStream_t);                                      \
   template void compact_columns<T>(const CsrView<T>&, const int32_t*, int64_t*, int32_t*, T*, int64_t*, DevBuf&,    \
-                                   hipStream_t);                                                                    \
+                                   hipStream_t, int32_t*, T*);                                                      \
+  template void sums_by_column<T>(const int32_t*, const T*, int64_t, int64_t, int64_t*, int32_t*, T*, double*, double*, DevBuf&,   \
+                                  hipStream_t);                                                                     \
   template void select_rows<T>(const CsrView<T>&, const int32_t*, int64_t, int64_t*, int32_t*, T*, int64_t*,        \
                                DevBuf&, hipStream_t);                                                               \
   template void build_tile_index<T>(const CsrView<T>&, int, int, int32_t*, hipStream_t);
