@@ -187,9 +187,34 @@ __global__ void row_sums_kernel(const int64_t* __restrict__ ptr, const T* __rest
   }
 }
 
+// The column map as the kernels below hold it in LDS: one bit per column (kept) and, per 32 columns, the number of kept
+// columns before them -- o2m[c] = before[c / 32] + popcount(bits[c / 32] below c % 32) -- instead of a 4-byte gather from L2
+// per stored entry.  `words` = ceil(n / 32); dynamic LDS: 2 * words * 4 bytes.
+__device__ __forceinline__ void load_column_map(const int32_t* __restrict__ o2m, int64_t n, int words, uint32_t* bits, uint32_t* before) {
+  for (int w = threadIdx.x; w < words; w += blockDim.x) {
+    uint32_t b = 0u;
+    int first = -1;
+    for (int k = 0; k < 32; ++k) {
+      const int64_t c = (int64_t)w * 32 + k;
+      const int32_t mi = c < n ? o2m[c] : -1;
+      if (mi >= 0) {
+        b |= 1u << k;
+        if (first < 0) first = mi;
+      }
+    }
+    bits[w] = b;
+    before[w] = first >= 0 ? (uint32_t)first : 0u;   // (kept columns are numbered in ascending order: the first kept one of the word)
+  }
+  __syncthreads();
+}
+
 template <typename T>
 __global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows,
-                                  const int32_t* __restrict__ o2m, int64_t* __restrict__ cnt) {
+                                  const int32_t* __restrict__ o2m, int64_t n, int words, int64_t* __restrict__ cnt) {
+  extern __shared__ uint32_t cmap_lds[];
+  uint32_t* bits = cmap_lds;
+  uint32_t* before = cmap_lds + words;
+  if (words > 0) load_column_map(o2m, n, words, bits, before);   // (words == 0: the map does not fit LDS, gather o2m instead)
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
@@ -201,7 +226,8 @@ __global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
 #pragma unroll
       for (int u = 0; u < 8; ++u) col[u] = eb + u * WAVE < e1 ? idx[eb + u * WAVE] : -1;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) c += col[u] >= 0 ? (o2m[col[u]] >= 0) : 0;
+      for (int u = 0; u < 8; ++u)
+        if (col[u] >= 0) c += words > 0 ? (int)((bits[col[u] >> 5] >> (col[u] & 31)) & 1u) : (int)(o2m[col[u]] >= 0);
     }
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) c += __shfl_xor(c, off);
@@ -214,9 +240,13 @@ __global__ void count_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
 // row after row (row r's start: the entries before it that were not kept, ptr[r] - new_ptr[r])
 template <typename T>
 __global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                  const T* __restrict__ val, int64_t rows, const int32_t* __restrict__ o2m,
+                                  const T* __restrict__ val, int64_t rows, const int32_t* __restrict__ o2m, int64_t n, int words,
                                   const int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_idx,
                                   T* __restrict__ new_val, int32_t* __restrict__ drop_col, T* __restrict__ drop_val) {
+  extern __shared__ uint32_t cmap_lds[];
+  uint32_t* bits = cmap_lds;
+  uint32_t* before = cmap_lds + words;
+  if (words > 0) load_column_map(o2m, n, words, bits, before);
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
@@ -234,14 +264,22 @@ __global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
         v[u] = e < e1 ? val[e] : (T)0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) mi[u] = col[u] >= 0 ? o2m[col[u]] : -1;
+      for (int u = 0; u < 4; ++u) {
+        mi[u] = -1;
+        if (col[u] >= 0 && words > 0) {
+          const uint32_t b = bits[col[u] >> 5], k = (uint32_t)col[u] & 31u;
+          if ((b >> k) & 1u) mi[u] = (int)(before[col[u] >> 5] + (uint32_t)__popc(b & ((1u << k) - 1u)));
+        } else if (col[u] >= 0) {
+          mi[u] = o2m[col[u]];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const unsigned long long keep = __ballot(mi[u] >= 0);
-        const int before = __popcll(keep & ((1ull << lane) - 1ull));
+        const int bef = __popcll(keep & ((1ull << lane) - 1ull));
         if (mi[u] >= 0) {
-          new_idx[out + before] = mi[u];
-          new_val[out + before] = v[u];
+          new_idx[out + bef] = mi[u];
+          new_val[out + bef] = v[u];
         }
         out += __popcll(keep);
         if (drop_col) {
@@ -488,10 +526,14 @@ void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s) {
 template <typename T>
 void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
                      int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col, T* drop_val) {
-  const int g = grid_for(A.rows * WAVE, 256, 4096);
-  hipLaunchKernelGGL((count_kept_kernel<T>), dim3(g), dim3(256), 0, s, A.ptr, A.idx, A.rows, o2m, new_ptr);
+  // (every workgroup rebuilds the column map in LDS from o2m: few, long-lived workgroups)
+  const int g = grid_for(A.rows * WAVE, 256, 2048);
+  int words = (int)std::min<int64_t>((A.cols + 31) / 32, 1 << 30);
+  size_t lds = (size_t)2 * words * sizeof(uint32_t);
+  if (lds > 48 * 1024) { words = 0; lds = 0; }   // more than 196608 columns: the kernels gather o2m from memory
+  hipLaunchKernelGGL((count_kept_kernel<T>), dim3(g), dim3(256), lds, s, A.ptr, A.idx, A.rows, o2m, A.cols, words, new_ptr);
   exclusive_scan_i64(new_ptr, A.rows + 1, scratch, 0, s);
-  hipLaunchKernelGGL((write_kept_kernel<T>), dim3(g), dim3(256), 0, s, A.ptr, A.idx, A.val, A.rows, o2m, new_ptr,
+  hipLaunchKernelGGL((write_kept_kernel<T>), dim3(g), dim3(256), lds, s, A.ptr, A.idx, A.val, A.rows, o2m, A.cols, words, new_ptr,
                      new_idx, new_val, drop_col, drop_val);
   SAPCA_HIP(hipGetLastError());
   SAPCA_HIP(hipMemcpyAsync(new_nnz_host, new_ptr + A.rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
