@@ -181,21 +181,21 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   const bool serial = getenv("SAPCA_PREPARE_SERIAL") != nullptr;
   const bool masked_aside = masked && n_used > 0 && !serial;
   const bool try_direct = sizeof(T) == 4 && at_tile_major && !masked && !serial;   // A^T's format without a transposed CSR
-  // Masked fits on the staged sweep take the same bucket route on the COMPACTED matrix (no transposition of the whole
-  // matrix, no row selection of A^T): the compaction then runs here, ahead of both format builds; the sums of the
-  // masked-out columns (mean_ is full width, sparse_masked/mod.rs:279-286) come from transposing only those columns.
+  // Masked fits compact first (MaskedCSRMatrix::new, sparse_masked/mod.rs:313) and transpose only what the mask keeps.  The
+  // entries the compaction drops leave as (column, value) pairs: the sums of the masked-out columns (mean_ is full width,
+  // sparse_masked/mod.rs:279-286) come from a stable sort of those pairs by column.  On the staged sweep (f32) the
+  // compacted matrix then takes the bucket route to A^T's format; otherwise it is transposed into a CSR.
   const bool try_masked_direct = sizeof(T) == 4 && at_tile_major && masked_aside && n_used <= 65536 && getenv("SAPCA_AT_SORT") == nullptr;
   bool compaction_done = false;
   int32_t* drop_col = nullptr;
   T* drop_val = nullptr;
-  if (try_masked_direct) {
+  if (masked_aside && getenv("SAPCA_MASK_TRANSPOSE_FIRST") == nullptr) {
     Scope sc(h, C_PREPARE);
     int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
     int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    // (the entries that are not kept leave as (column, value) pairs: their column sums are taken below)
-    drop_col = from_upload ? nullptr : h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
-    drop_val = from_upload ? nullptr : h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    drop_col = from_upload ? nullptr : h.drop_col.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    drop_val = from_upload ? nullptr : h.drop_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
     k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val);
     h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
     compaction_done = true;
@@ -251,7 +251,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   bool masked_direct = false;
   if constexpr (sizeof(T) == 4) {
-    if (compaction_done && nnz_used > 0) {
+    if (compaction_done && try_masked_direct && nnz_used > 0) {
       Scope sc(h, C_PREPARE);
       double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
       int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
@@ -274,7 +274,32 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     }
   }
 
-  if (!at_direct && !masked_direct) {
+  // masked, off the bucket route: the compacted matrix transposed into a CSR (tile-major rows where the staged sweep's format
+  // is built from them), the kept columns' sums as its row sums, the masked-out columns' from the dropped pairs
+  bool masked_compact = false;
+  if (compaction_done && !masked_direct) {
+    Scope sc(h, C_PREPARE);
+    double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+    int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
+    int32_t* cat_idx = h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    T* cat_val = h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    k::transpose_csr(view(h.a_used), cat_ptr, cat_idx, cat_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp) : 0,
+                     nullptr);
+    h.at_used = {n_used, m, nnz_used, cat_ptr, cat_idx, cat_val};
+    if (!from_upload) {
+      double* d_part = h.scratch2.as<double>((size_t)2 * n_used + 2);
+      k::row_sums(view(h.at_used), d_part, d_part + n_used, s);
+      SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
+      k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                        h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                        d_stats, d_stats + n, h.scratch, s);
+      k::scatter_pairs(d_part, d_part + n_used, d_sel, n_used, d_stats, d_stats + n, s);
+    }
+    At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = nullptr; At.idx = nullptr; At.val = nullptr;
+    masked_compact = true;
+  }
+
+  if (!at_direct && !masked_direct && !masked_compact) {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
     int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
@@ -312,7 +337,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       SAPCA_HIP(hipMemcpyAsync(d_stats, h.up_stats.out.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
     } else if (at_direct) {
       k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);   // (the sums came out of the format build)
-    } else if (masked_direct) {
+    } else if (masked_direct || masked_compact) {
       // (sums in place; the per-column counts are only read by the unmasked projection)
     } else {
       if constexpr (sizeof(T) == 4) {
@@ -347,8 +372,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   // operator seen by the SVD engines: MaskedCSRMatrix::new (sparse_masked/mod.rs:313)
   int64_t nnz_used_t = 0;
-  if (masked_direct) {
-    nnz_used_t = nnz_used;   // (a_used and at_used were set on the bucket route)
+  if (masked_direct || masked_compact) {
+    nnz_used_t = nnz_used;   // (a_used and at_used were set above)
   } else if (masked) {
     Scope sc(h, C_PREPARE);
     if (!masked_aside && !compaction_done) {

@@ -74,6 +74,7 @@ struct sapca_handle_s {
   hipEvent_t up_stats_done = nullptr;
   sapca::DevBuf at_ptr, at_idx, at_val;                          // A^T
   sapca::DevBuf ca_ptr, ca_idx, ca_val, cat_ptr, cat_idx, cat_val;  // mask-compacted A, A^T
+  sapca::DevBuf drop_col, drop_val;                                // the entries the compaction dropped, as (column, value) pairs
   sapca::DevBuf scratch, scratch2;
   sapca::DevBuf panel_x, panel_y, panel_w;
   sapca::DevBuf small;                                           // G, R1, R2, Rinv, M, cvec, svec, info
