@@ -82,6 +82,7 @@ struct sapca_handle_s {
   sapca::DevBuf mean_used_dev, o2m_dev, sel_rows_dev;
   sapca::DevBuf components_dev;                                  // k x n_used, T
   sapca::DevBuf lanczos_buf;
+  sapca::DevBuf idx16_a, idx16_b;                                 // 2-byte index copies of the two operators of a Lanczos step
   sapca::TiledBuffers tb_a, tb_at;                               // tile-major formats for the LDS-staged sweep
   sapca::TiledOp tiled_a, tiled_at;
   sapca::DevBuf split_scratch;

@@ -60,9 +60,11 @@ spmv_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, co
 
 // The same with x staged in LDS (operators with up to ~19k columns: the masked C3 matrix has 18k): the
 // per-entry gather then costs an LDS read instead of an L2 sector, which is what bounds the kernel above.
-template <typename T>
+// I = uint16_t: the column indices as a 2-byte copy (x fits LDS, so it has fewer than 65536 elements): 10 instead of 12
+// bytes per f64 entry (6 instead of 8 for f32) on a kernel that runs at the HBM rate, once per Lanczos step.
+template <typename T, typename I>
 __global__ void __launch_bounds__(1024)
-spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val, int64_t rows,
+spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const I* __restrict__ idx, const T* __restrict__ val, int64_t rows,
                  int64_t cols, const double* __restrict__ x, double* __restrict__ y) {
   extern __shared__ double xs[];
   for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) xs[i] = x[i];
@@ -160,10 +162,12 @@ spmv_sliced_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
 // row group inside that slice, so x is read once per row group instead of once per workgroup (C3: 38 MB
 // instead of 410 MB beside the 1.3 GB of entries); the per-slice partial sums go to part[slice][row] and a
 // second kernel adds them in slice order.  Lane j of a wave holds the run limits of the wave's j-th row.
-template <typename T>
+// REL16: the entry stream reads `rel` = column mod slice as 2-byte values (the position inside the staged slice) instead of
+// the 4-byte columns; the run limits are still searched in `idx`.
+template <typename T, bool REL16>
 __global__ void __launch_bounds__(SLICE_WAVES * WAVE)
-spmv_slice_grid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val,
-                       int64_t rows, int64_t cols, int slice, int nslices, int rows_per_group,
+spmv_slice_grid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const uint16_t* __restrict__ rel,
+                       const T* __restrict__ val, int64_t rows, int64_t cols, int slice, int nslices, int rows_per_group,
                        const double* __restrict__ x, double* __restrict__ part) {
   extern __shared__ double xs[];
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
@@ -200,16 +204,22 @@ spmv_slice_grid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restric
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int64_t e = e0 + lane;
     for (; e + 3 * WAVE < e1; e += 4 * WAVE) {
-      const int k0 = __builtin_nontemporal_load(idx + e), k1 = __builtin_nontemporal_load(idx + e + WAVE);
-      const int k2 = __builtin_nontemporal_load(idx + e + 2 * WAVE), k3 = __builtin_nontemporal_load(idx + e + 3 * WAVE);
+      int k0, k1, k2, k3;
+      if constexpr (REL16) {
+        k0 = __builtin_nontemporal_load(rel + e); k1 = __builtin_nontemporal_load(rel + e + WAVE);
+        k2 = __builtin_nontemporal_load(rel + e + 2 * WAVE); k3 = __builtin_nontemporal_load(rel + e + 3 * WAVE);
+      } else {
+        k0 = __builtin_nontemporal_load(idx + e) - (int)c0; k1 = __builtin_nontemporal_load(idx + e + WAVE) - (int)c0;
+        k2 = __builtin_nontemporal_load(idx + e + 2 * WAVE) - (int)c0; k3 = __builtin_nontemporal_load(idx + e + 3 * WAVE) - (int)c0;
+      }
       const T v0 = __builtin_nontemporal_load(val + e), v1 = __builtin_nontemporal_load(val + e + WAVE);
       const T v2 = __builtin_nontemporal_load(val + e + 2 * WAVE), v3 = __builtin_nontemporal_load(val + e + 3 * WAVE);
-      a0 = fma((double)v0, xs[k0 - c0], a0);
-      a1 = fma((double)v1, xs[k1 - c0], a1);
-      a2 = fma((double)v2, xs[k2 - c0], a2);
-      a3 = fma((double)v3, xs[k3 - c0], a3);
+      a0 = fma((double)v0, xs[k0], a0);
+      a1 = fma((double)v1, xs[k1], a1);
+      a2 = fma((double)v2, xs[k2], a2);
+      a3 = fma((double)v3, xs[k3], a3);
     }
-    for (; e < e1; e += WAVE) a0 = fma((double)val[e], xs[idx[e] - c0], a0);
+    for (; e < e1; e += WAVE) a0 = fma((double)val[e], xs[REL16 ? (int)rel[e] : idx[e] - (int)c0], a0);
     double a = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) a += __shfl_xor(a, off);
@@ -339,15 +349,64 @@ inline unsigned grid1(int64_t n, int block = 256, int64_t cap = 1 << 30) {
   return (unsigned)std::max<int64_t>(1, std::min(g, cap));
 }
 
+// which kernel spmv_launch takes for an operator, and the slice of x its 2-byte index copy is relative to (0: absolute)
+enum SpmvKind { SPMV_ROW = 0, SPMV_LDSX, SPMV_SLICE_GRID, SPMV_SLICED };
 template <typename T>
-void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s, DevBuf* scratch = nullptr) {
+SpmvKind spmv_plan(const CsrView<T>& A, bool has_scratch, int* slice_out = nullptr, int* nslices_out = nullptr) {
+  static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
+  static const bool no_grid = getenv("SAPCA_SPMV_NO_SLICE_GRID") != nullptr;
+  const size_t xbytes = (size_t)A.cols * sizeof(double);
+  if (A.rows == 0 || no_lds) return SPMV_ROW;
+  if (xbytes <= 150 * 1024 && A.rows >= 4096) return SPMV_LDSX;
+  if (A.nnz >= 256 * A.rows && A.rows >= 1024) {
+    const int max_slice = 150 * 1024 / (int)sizeof(double);
+    const int nslices = (int)((A.cols + max_slice - 1) / max_slice);
+    const int slice = (int)((A.cols + nslices - 1) / nslices);
+    if (slice_out) *slice_out = slice;
+    if (nslices_out) *nslices_out = nslices;
+    if (has_scratch && !no_grid && nslices > 1) return SPMV_SLICE_GRID;
+    return SPMV_SLICED;
+  }
+  return SPMV_ROW;
+}
+
+__global__ void narrow_idx16_kernel(const int32_t* __restrict__ idx, int64_t count, int mod, uint16_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride)
+    out[e] = (uint16_t)(mod > 0 ? idx[e] % mod : idx[e]);
+}
+
+// the 2-byte index copy an operator's Lanczos kernel reads (nullptr: that kernel takes the 4-byte columns)
+template <typename T>
+const uint16_t* spmv_narrow_indices(const CsrView<T>& A, bool has_scratch, DevBuf& buf, hipStream_t s) {
+  static const bool off = getenv("SAPCA_SPMV_IDX32") != nullptr;
+  int slice = 0, nslices = 0;
+  const SpmvKind kind = spmv_plan(A, has_scratch, &slice, &nslices);
+  if (off || A.nnz == 0 || (kind != SPMV_LDSX && kind != SPMV_SLICE_GRID)) return nullptr;
+  if (kind == SPMV_LDSX && A.cols > 65536) return nullptr;
+  if (kind == SPMV_SLICE_GRID && slice > 65536) return nullptr;
+  uint16_t* out = buf.as<uint16_t>((size_t)A.nnz);
+  hipLaunchKernelGGL(narrow_idx16_kernel, dim3((unsigned)std::min<int64_t>((A.nnz + 255) / 256, 8192)), dim3(256), 0, s, A.idx, A.nnz,
+                     kind == SPMV_SLICE_GRID ? slice : 0, out);
+  SAPCA_HIP(hipGetLastError());
+  return out;
+}
+
+template <typename T>
+void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s, DevBuf* scratch = nullptr,
+                 const uint16_t* idx16 = nullptr) {
   if (A.rows == 0) return;
   const size_t xbytes = (size_t)A.cols * sizeof(double);
   static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
   if (!no_lds && xbytes <= 150 * 1024 && A.rows >= 4096) {
-    static LdsAttrState attr;   // one per instantiation of this function template
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T>), 150 * 1024, attr);
-    hipLaunchKernelGGL((spmv_ldsx_kernel<T>), dim3(256), dim3(1024), xbytes, s, A.ptr, A.idx, A.val, A.rows, A.cols, x, y);
+    static LdsAttrState attr, attr16;   // one per instantiation of this function template
+    if (idx16) {
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T, uint16_t>), 150 * 1024, attr16);
+      hipLaunchKernelGGL((spmv_ldsx_kernel<T, uint16_t>), dim3(256), dim3(1024), xbytes, s, A.ptr, idx16, A.val, A.rows, A.cols, x, y);
+    } else {
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T, int32_t>), 150 * 1024, attr);
+      hipLaunchKernelGGL((spmv_ldsx_kernel<T, int32_t>), dim3(256), dim3(1024), xbytes, s, A.ptr, A.idx, A.val, A.rows, A.cols, x, y);
+    }
     return;
   }
   if (!no_lds && A.nnz >= 256 * A.rows && A.rows >= 1024) {   // long rows: slices of x through LDS
@@ -361,11 +420,18 @@ void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s,
       const int rows_per_group = (int)std::min<int64_t>(SLICE_WAVES * WAVE, (A.rows + groups_one_round - 1) / groups_one_round);
       const int64_t groups = (A.rows + rows_per_group - 1) / rows_per_group;
       double* part = scratch->as<double>((size_t)nslices * A.rows);
-      static LdsAttrState attr3;
-      ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_slice_grid_kernel<T>), 150 * 1024, attr3);
-      hipLaunchKernelGGL((spmv_slice_grid_kernel<T>), dim3((unsigned)(groups * nslices)), dim3(SLICE_WAVES * WAVE),
-                         (size_t)slice * sizeof(double), s, A.ptr, A.idx, A.val, A.rows, A.cols, slice, nslices, rows_per_group, x,
-                         part);
+      static LdsAttrState attr3, attr3r;
+      if (idx16) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_slice_grid_kernel<T, true>), 150 * 1024, attr3r);
+        hipLaunchKernelGGL((spmv_slice_grid_kernel<T, true>), dim3((unsigned)(groups * nslices)), dim3(SLICE_WAVES * WAVE),
+                           (size_t)slice * sizeof(double), s, A.ptr, A.idx, idx16, A.val, A.rows, A.cols, slice, nslices, rows_per_group,
+                           x, part);
+      } else {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_slice_grid_kernel<T, false>), 150 * 1024, attr3);
+        hipLaunchKernelGGL((spmv_slice_grid_kernel<T, false>), dim3((unsigned)(groups * nslices)), dim3(SLICE_WAVES * WAVE),
+                           (size_t)slice * sizeof(double), s, A.ptr, A.idx, (const uint16_t*)nullptr, A.val, A.rows, A.cols, slice,
+                           nslices, rows_per_group, x, part);
+      }
       hipLaunchKernelGGL(slice_sum_kernel, dim3(grid1(A.rows)), dim3(256), 0, s, part, A.rows, nslices, y);
       return;
     }
@@ -438,14 +504,17 @@ void lanczos_fit(sapca_handle_s& h) {
   hipLaunchKernelGGL(norm2_kernel, dim3(nparts), dim3(256), 0, s, w, len, partial);
   hipLaunchKernelGGL(scale_kernel, dim3(grid1(len, 256, 1024)), dim3(256), 0, s, w, len, partial, nparts, beta + jmax + 1, V);
 
+  // 2-byte index copies for the two products of a step (one pass over the indices each, paid back in a few steps)
+  const uint16_t* first16 = spmv_narrow_indices(right_side ? A : At, false, h.idx16_a, s);
+  const uint16_t* second16 = spmv_narrow_indices(right_side ? At : A, true, h.idx16_b, s);
   auto apply_B = [&](const double* v, double* out) {  // out = A^T A v  (or A A^T v)
     if (right_side) {
-      spmv_launch(A, v, tmp, s);
-      spmv_launch(At, tmp, out, s, &h.scratch2);
+      spmv_launch(A, v, tmp, s, nullptr, first16);
+      spmv_launch(At, tmp, out, s, &h.scratch2, second16);
       if (h.comm.active()) h.comm.allreduce(out, (uint64_t)len, 1, s);
     } else {
-      spmv_launch(At, v, tmp, s);
-      spmv_launch(A, tmp, out, s, &h.scratch2);
+      spmv_launch(At, v, tmp, s, nullptr, first16);
+      spmv_launch(A, tmp, out, s, &h.scratch2, second16);
     }
   };
 
