@@ -620,6 +620,7 @@ void sapca_destroy(sapca_handle h) {
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_drop) (void)hipEventDestroy(h->ev_drop);
   if (h->up_stats_done) (void)hipEventDestroy(h->up_stats_done);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;

@@ -199,6 +199,24 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val);
     h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
     compaction_done = true;
+    if (!from_upload) {
+      // the masked-out columns' sums on the side stream, beside the transposition / the bucket route of the kept part
+      // (sum | sumsq of every column, zero where a column is kept; the kept columns' sums are scattered on top later)
+      if (!h.stream2) {
+        SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
+      }
+      if (!h.ev_drop) SAPCA_HIP(hipEventCreateWithFlags(&h.ev_drop, hipEventDisableTiming));
+      double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+      SAPCA_HIP(hipEventRecord(h.ev_drop, s));   // (the compaction synchronised: this only orders the side stream after it)
+      SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_drop, 0));
+      SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), h.stream2));
+      k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                        h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                        d_stats, d_stats + n, h.split_scratch, h.stream2);
+      SAPCA_HIP(hipEventRecord(h.ev_drop, h.stream2));
+    }
   }
   if (masked_aside || try_direct) {
     if (!h.stream2) {
@@ -263,10 +281,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         if (!from_upload) {
           // sums of every column from the pairs the compaction dropped (zero where a column is kept), then the kept
           // columns' sums from the bucket route on top; the per-column counts are only read by the unmasked projection
-          SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
-          k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
-                            h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
-                            d_stats, d_stats + n, h.scratch, s);
+          SAPCA_HIP(hipStreamWaitEvent(s, h.ev_drop, 0));   // (the dropped pairs' sums, from the side stream)
           k::scatter_pairs(d_part, d_part + n_used, d_sel, n_used, d_stats, d_stats + n, s);
         }
         At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = nullptr; At.idx = nullptr; At.val = nullptr;
@@ -289,10 +304,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     if (!from_upload) {
       double* d_part = h.scratch2.as<double>((size_t)2 * n_used + 2);
       k::row_sums(view(h.at_used), d_part, d_part + n_used, s);
-      SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
-      k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
-                        h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
-                        d_stats, d_stats + n, h.scratch, s);
+      SAPCA_HIP(hipStreamWaitEvent(s, h.ev_drop, 0));   // (the dropped pairs' sums, from the side stream)
       k::scatter_pairs(d_part, d_part + n_used, d_sel, n_used, d_stats, d_stats + n, s);
     }
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = nullptr; At.idx = nullptr; At.val = nullptr;

@@ -14,7 +14,7 @@ struct sapca_handle_s {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t stream2 = nullptr;        // side stream: A's format is built beside the transposition (prepare)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_drop = nullptr;
 
   // builder state
   std::vector<uint8_t> mask;

@@ -6,8 +6,8 @@ import csv,glob
 f=glob.glob("/tmp/ptl3/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-idx=[i for i,r in enumerate(rows) if "pack_rows" in r["Kernel_Name"]]
-i0=idx[-1]-1
+idx=[i for i,r in enumerate(rows) if "count_kept" in r["Kernel_Name"]]
+i0=idx[-1]
 t0=int(rows[i0]["Start_Timestamp"])
 n=0
 for r in rows[i0:]:
