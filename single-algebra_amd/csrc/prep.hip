@@ -122,21 +122,26 @@ __global__ void pack_rows_permuted_kernel(const int64_t* __restrict__ ptr, const
   }
 }
 
-// f64 matrices: the sort carries a 16-byte (row, value) payload instead of a permutation that a random gather
-// has to resolve afterwards (6.6 ms of an 9.3 ms transposition at C3)
-struct alignas(16) RowVal64 {
-  uint32_t row;
-  uint32_t pad;
-  double val;
+// f64 matrices: the sort carries a 12-byte (row, value) payload instead of a permutation that a random gather
+// has to resolve afterwards (6.6 ms of an 9.3 ms transposition at C3); three 4-byte words, so that a sort pass moves
+// 14 bytes per entry with 16-bit keys (fewer than 65536 columns) instead of 20
+struct RowVal64 {
+  uint32_t row, lo, hi;
 };
-__global__ void pack_rows64_kernel(const int64_t* __restrict__ ptr, const double* __restrict__ val, int64_t rows,
-                                   RowVal64* __restrict__ packed) {
+static_assert(sizeof(RowVal64) == 12, "packed payload");
+template <typename K>   // K = uint16_t: also writes the keys (the column indices) as 2-byte values; uint32_t: the sort reads A.idx itself
+__global__ void pack_rows64_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                   int64_t rows, K* __restrict__ keys, RowVal64* __restrict__ packed) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
   for (int64_t r = wave; r < rows; r += nwaves) {
     const int64_t e1 = ptr[r + 1];
-    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) packed[e] = RowVal64{(uint32_t)r, 0u, val[e]};
+    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(val[e]);
+      packed[e] = RowVal64{(uint32_t)r, (uint32_t)b, (uint32_t)(b >> 32)};
+      if constexpr (sizeof(K) == 2) keys[e] = (K)idx[e];
+    }
   }
 }
 __global__ void unpack_rows64_kernel(const RowVal64* __restrict__ packed, int64_t count, int32_t* __restrict__ t_idx,
@@ -146,7 +151,7 @@ __global__ void unpack_rows64_kernel(const RowVal64* __restrict__ packed, int64_
   for (; i < count; i += stride) {
     const RowVal64 p = packed[i];
     t_idx[i] = (int32_t)p.row;
-    t_val[i] = p.val;
+    t_val[i] = __longlong_as_double((long long)(((unsigned long long)p.hi << 32) | (unsigned long long)p.lo));
   }
 }
 
@@ -468,21 +473,37 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
   if constexpr (sizeof(T) == 8) {
     static const bool gather_route = getenv("SAPCA_TRANSPOSE_GATHER") != nullptr;
     if (!gather_route) {
+      const bool k16 = bits <= 16;
       size_t sb = 0;
-      SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const RowVal64*)nullptr,
-                                          (RowVal64*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
-      const size_t a4 = (size_t)round_up(nnz * 4, 256), a16 = (size_t)round_up(nnz * 16, 256);
-      char* base = static_cast<char*>(scratch.ensure(a4 + 2 * a16 + sb + 256));
+      if (k16)
+        SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sb, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const RowVal64*)nullptr,
+                                            (RowVal64*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
+      else
+        SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const RowVal64*)nullptr,
+                                            (RowVal64*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
+      const size_t a4 = (size_t)round_up(nnz * 4, 256), a12 = (size_t)round_up(nnz * 12, 256);
+      char* base = static_cast<char*>(scratch.ensure(2 * a4 + 2 * a12 + sb + 256));
       uint32_t* keys_out = reinterpret_cast<uint32_t*>(base);
-      RowVal64* packed = reinterpret_cast<RowVal64*>(base + a4);
-      RowVal64* packed_out = reinterpret_cast<RowVal64*>(base + a4 + a16);
-      void* tmp = base + a4 + 2 * a16;
-      hipLaunchKernelGGL(pack_rows64_kernel, dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr,
-                         reinterpret_cast<const double*>(A.val), A.rows, packed);
-      SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, reinterpret_cast<const uint32_t*>(A.idx), keys_out, packed, packed_out,
-                                          (size_t)nnz, 0u, (unsigned)bits, s));
-      hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out,
-                         nnz, A.cols, t_ptr);
+      uint32_t* keys_in = reinterpret_cast<uint32_t*>(base + a4);      // (16-bit keys only)
+      RowVal64* packed = reinterpret_cast<RowVal64*>(base + 2 * a4);
+      RowVal64* packed_out = reinterpret_cast<RowVal64*>(base + 2 * a4 + a12);
+      void* tmp = base + 2 * a4 + 2 * a12;
+      if (k16) {
+        uint16_t* k_in = reinterpret_cast<uint16_t*>(keys_in);
+        uint16_t* k_out = reinterpret_cast<uint16_t*>(keys_out);
+        hipLaunchKernelGGL((pack_rows64_kernel<uint16_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,
+                           reinterpret_cast<const double*>(A.val), A.rows, k_in, packed);
+        SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, k_in, k_out, packed, packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+        hipLaunchKernelGGL((lower_bound_kernel<uint16_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, k_out, nnz,
+                           A.cols, t_ptr);
+      } else {
+        hipLaunchKernelGGL((pack_rows64_kernel<uint32_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,
+                           reinterpret_cast<const double*>(A.val), A.rows, (uint32_t*)nullptr, packed);
+        SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, reinterpret_cast<const uint32_t*>(A.idx), keys_out, packed, packed_out,
+                                            (size_t)nnz, 0u, (unsigned)bits, s));
+        hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out,
+                           nnz, A.cols, t_ptr);
+      }
       hipLaunchKernelGGL(unpack_rows64_kernel, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, s, packed_out, nnz, t_idx,
                          reinterpret_cast<double*>(t_val));
       SAPCA_HIP(hipGetLastError());
