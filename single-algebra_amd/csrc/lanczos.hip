@@ -277,6 +277,31 @@ gemv_n_sub_kernel(const double* __restrict__ V, int64_t len, int nvec, const dou
   w[r] -= s;
 }
 
+// The second Gram-Schmidt pass fused with what follows it: w -= V^T h2, the partial sums of ||w||^2 of this block's
+// elements (for scale_kernel), and alpha[j] = h1[j] + h2[j] (the diagonal of T is the projection on v_j itself).
+__global__ void __launch_bounds__(256)
+gemv_n_sub_norm_kernel(const double* __restrict__ V, int64_t len, int nvec, const double* __restrict__ h1,
+                       const double* __restrict__ h2, double* __restrict__ w, double* __restrict__ partial, int j,
+                       double* __restrict__ alpha) {
+  __shared__ double red[4];
+  double acc = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < len; r += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0;
+    for (int i = 0; i < nvec; ++i) s = fma(h2[i], V[(int64_t)i * len + r], s);
+    const double x = w[r] - s;
+    w[r] = x;
+    acc = fma(x, x, acc);
+  }
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (blockIdx.x == 0) alpha[j] = h1[j] + h2[j];
+  }
+}
+
 // beta = ||w||; out[j] = beta; vnext = w / beta  (single block computes the norm, then all scale)
 __global__ void __launch_bounds__(256)
 norm2_kernel(const double* __restrict__ w, int64_t len, double* __restrict__ partial) {
@@ -294,7 +319,7 @@ norm2_kernel(const double* __restrict__ w, int64_t len, double* __restrict__ par
 __global__ void __launch_bounds__(256)
 scale_kernel(const double* __restrict__ w, int64_t len, const double* __restrict__ partial, int nparts,
              double* __restrict__ beta_out, double* __restrict__ vnext) {
-  // the partial sums of norm2_kernel, reduced in a fixed order by every wave (nparts <= 256)
+  // the partial sums of ||w||^2 (norm2_kernel or the fused second Gram-Schmidt pass), reduced in a fixed order by every wave
   const int lane = threadIdx.x & (WAVE - 1);
   double s = 0;
   for (int i = lane; i < nparts; i += WAVE) s += partial[i];
@@ -305,12 +330,6 @@ scale_kernel(const double* __restrict__ w, int64_t len, const double* __restrict
   const double inv = beta > 0 ? 1.0 / beta : 0.0;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < len; r += (int64_t)gridDim.x * blockDim.x)
     vnext[r] = w[r] * inv;
-}
-
-// alpha[j] = h1[j] + h2[j]  (the diagonal of T is the projection on v_j itself)
-__global__ void pick_alpha_kernel(const double* __restrict__ h1, const double* __restrict__ h2, int j,
-                                  double* __restrict__ alpha) {
-  alpha[j] = h1[j] + h2[j];
 }
 
 // out[r][i] = sum_j V[j][r] S[j][i]   (Ritz vectors; out row-major len x ldo as T)
@@ -530,10 +549,9 @@ void lanczos_fit(sapca_handle_s& h) {
     hipLaunchKernelGGL(gemv_t_kernel, dim3(nvec), dim3(GEMV_T_THREADS), 0, s, V, len, nvec, w, h1, 0);
     hipLaunchKernelGGL(gemv_n_sub_kernel, dim3(grid1(len)), dim3(256), 0, s, V, len, nvec, h1, w);
     hipLaunchKernelGGL(gemv_t_kernel, dim3(nvec), dim3(GEMV_T_THREADS), 0, s, V, len, nvec, w, h2, 0);
-    hipLaunchKernelGGL(gemv_n_sub_kernel, dim3(grid1(len)), dim3(256), 0, s, V, len, nvec, h2, w);
-    hipLaunchKernelGGL(pick_alpha_kernel, dim3(1), dim3(1), 0, s, h1, h2, (int)j, alpha);
-    hipLaunchKernelGGL(norm2_kernel, dim3(nparts), dim3(256), 0, s, w, len, partial);
-    hipLaunchKernelGGL(scale_kernel, dim3(grid1(len, 256, 1024)), dim3(256), 0, s, w, len, partial, nparts, beta + j,
+    const int nb2 = (int)std::min<int64_t>((len + 255) / 256, 1024);   // (one partial sum of ||w||^2 per block: at most the 1024 slots)
+    hipLaunchKernelGGL(gemv_n_sub_norm_kernel, dim3(nb2), dim3(256), 0, s, V, len, nvec, h1, h2, w, partial, (int)j, alpha);
+    hipLaunchKernelGGL(scale_kernel, dim3(grid1(len, 256, 1024)), dim3(256), 0, s, w, len, partial, nb2, beta + j,
                        V + (size_t)(j + 1) * len);
     steps = j + 1;
     const bool last = steps == jmax;
