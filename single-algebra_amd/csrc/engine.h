@@ -54,6 +54,7 @@ struct sapca_handle_s {
   // the column sums on the host (sum | sumsq | row count), copied asynchronously: single-rank fits read them at the end
   // of fit() instead of stalling the stream between the preparation and the first sweep
   sapca::PinnedBuf stats_host;
+  sapca::PinnedBuf lanczos_host;  // alpha | beta of the Lanczos tridiagonal, read back at each convergence check
   bool stats_pending = false;
   int64_t stats_cols = 0;
   double m_local = 0;

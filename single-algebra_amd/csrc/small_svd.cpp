@@ -211,10 +211,14 @@ bool sym_eigh_desc(const std::vector<double>& A, int n, std::vector<double>& w, 
   return true;
 }
 
-bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z) {
+bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z, bool last_row_only) {
   // Implicit QL with Wilkinson shifts (EISPACK tql2 structure).  e[i] couples (i-1, i), e[0] unused.
-  Z.assign((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) Z[(size_t)i * n + i] = 1.0;
+  // last_row_only: the rotations are applied to the bottom row of Z alone (Z is then 1 x n): the same arithmetic as
+  // the full update restricted to that row, so a Lanczos error bound read from it does not depend on the mode.
+  const int zr = last_row_only ? 1 : n;        // rows of Z kept
+  const int k0 = last_row_only ? n - 1 : 0;    // first row of the full matrix they stand for
+  Z.assign((size_t)zr * n, 0.0);
+  for (int i = k0; i < n; ++i) Z[(size_t)(i - k0) * n + i] = 1.0;
   if (n == 0) return true;
   for (int i = 1; i < n; ++i) e[i - 1] = e[i];
   e[n - 1] = 0.0;
@@ -248,7 +252,7 @@ bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::ve
           p = s * r;
           d[i + 1] = g + p;
           g = c * r - b;
-          for (int k = 0; k < n; ++k) {
+          for (int k = 0; k < zr; ++k) {
             f = Z[(size_t)k * n + i + 1];
             Z[(size_t)k * n + i + 1] = s * Z[(size_t)k * n + i] + c * f;
             Z[(size_t)k * n + i] = c * Z[(size_t)k * n + i] - s * f;
@@ -265,10 +269,10 @@ bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::ve
   std::vector<int> order(n);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
-  std::vector<double> d2(n), Z2((size_t)n * n);
+  std::vector<double> d2(n), Z2((size_t)zr * n);
   for (int c = 0; c < n; ++c) {
     d2[c] = d[order[c]];
-    for (int k = 0; k < n; ++k) Z2[(size_t)k * n + c] = Z[(size_t)k * n + order[c]];
+    for (int k = 0; k < zr; ++k) Z2[(size_t)k * n + c] = Z[(size_t)k * n + order[c]];
   }
   d.swap(d2);
   Z.swap(Z2);

@@ -12,7 +12,7 @@ void jacobi_svd(const std::vector<double>& A, int l, std::vector<double>& U, std
 // Symmetric tridiagonal eigen-decomposition (implicit QL): d diagonal, e sub-diagonal (e[0] unused
 // convention: e[i] couples i-1 and i).  On return d holds eigenvalues (ascending) and Z (row-major
 // n x n) the eigenvectors in columns.  Returns false if it failed to converge.
-bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z);
+bool tridiag_eigh(std::vector<double>& d, std::vector<double>& e, int n, std::vector<double>& Z, bool last_row_only = false);
 
 // Eigen-decomposition of the symmetric row-major n x n matrix A (Householder tridiagonalisation + implicit
 // QL, eigenvectors accumulated in rows so that every rotation runs over contiguous memory).  On return w

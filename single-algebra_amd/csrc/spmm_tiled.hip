@@ -375,7 +375,6 @@ constexpr int Q_TILE_BYTES = 80 * 1024;          // default split of the 160 KiB
 constexpr int Q_MAX_TILES_RUNS = 16384;          // tile-major builder (bounded by the tile arithmetic's float reciprocal and the index tables' size)
 constexpr int Q_TILE_BYTES_BIG = 96 * 1024;      // for operators whose chunks leave room: fewer, longer tile steps
 constexpr int q_stage_bytes(int tile_bytes) { return LDS_TOTAL - tile_bytes - 1024; }
-constexpr int q_stage_entries(int tile_bytes) { return q_stage_bytes(tile_bytes) / 8 - WAVE; }
 constexpr int QBLOCK_ROWS = 1024;                // most rows of a quad-format block (the DPP-fed sweep with 16 row slots per lane group)
 constexpr int Q_BLOCK_QUADS = QBLOCK_ROWS / 4;   // stride of the per-chunk quad step table
 constexpr int ENT_SLACK = 4 * WAVE;             // zero entries behind the last chunk: the sweeps read whole 16-step chunks (and three ahead)
