@@ -12,6 +12,8 @@
 // stored entries of the row, so one wave-instruction gathers 64/LPR panel rows of 16*LPR bytes
 // each -- every panel access is a full, aligned 16-B-per-lane segment.  The slots are summed
 // with wavefront shuffles at the end of a row.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sapca {
@@ -121,6 +123,98 @@ spmm_rowgather_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same row walk for panels of 16 or 32 lanes per row, with the entry stream read once: a lane loads ONE entry of a
+// chunk (index, value, and the shift of its column), coalesced, and step t of the chunk reaches the 16 lanes of a DPP
+// row through row_newbcast:t -- one index/value/shift load per 16 (or 8) entries and lane instead of one per entry.
+// Slot s (a 16- or 32-lane group) takes entries [16 s, 16 s + 16) of a chunk; rows shorter than a chunk and the last
+// partial chunk go the per-entry way of the kernel above.
+// ---------------------------------------------------------------------------------------
+template <int STEP> __device__ __forceinline__ int bcast_row(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + STEP, 0xf, 0xf, false);   // row_newbcast:STEP
+}
+template <int STEP> __device__ __forceinline__ float bcast_row(float v) { return __int_as_float(bcast_row<STEP>(__float_as_int(v))); }
+template <int STEP> __device__ __forceinline__ double bcast_row(double v) {
+  const int lo = bcast_row<STEP>(__double2loint(v)), hi = bcast_row<STEP>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <typename T, int STEP>
+__device__ __forceinline__ void bcast_steps(int c, T v, const T* __restrict__ xq, int ldx, typename Vec<T>::type& acc0,
+                                            typename Vec<T>::type& acc1) {
+  using V = typename Vec<T>::type;
+  if constexpr (STEP < 16) {
+    const int ca = bcast_row<STEP>(c), cb = bcast_row<STEP + 1>(c);
+    const T va = bcast_row<STEP>(v), vb = bcast_row<STEP + 1>(v);
+    const V xa = *reinterpret_cast<const V*>(xq + (int64_t)ca * ldx);
+    const V xb = *reinterpret_cast<const V*>(xq + (int64_t)cb * ldx);
+    fma_vec<T>(acc0, va, xa);
+    fma_vec<T>(acc1, vb, xb);
+    bcast_steps<T, STEP + 2>(c, v, xq, ldx, acc0, acc1);
+  }
+}
+
+template <typename T, int LPR, bool SHIFT>
+__global__ void __launch_bounds__(256)
+spmm_rowbcast_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val,
+                     int64_t rows, const T* __restrict__ X, int ldx, T* __restrict__ Y, int ldy, int ncols,
+                     const T* __restrict__ cvec, int vec_store, const T* __restrict__ shift) {
+  static_assert(LPR == 16 || LPR == 32, "a slot is one or two DPP rows");
+  using V = typename Vec<T>::type;
+  constexpr int VEC = Vec<T>::N;
+  constexpr int SLOTS = WAVE / LPR;
+  constexpr int COVER = LPR * VEC;
+  constexpr int CHUNK = SLOTS * 16;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int q = lane % LPR;
+  const int slot = lane / LPR;
+  const int mine = slot * 16 + (lane & 15);      // the entry of a chunk this lane loads
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    for (int c0 = 0; c0 < ldx; c0 += COVER) {
+      const int col = c0 + q * VEC;
+      const bool live = col < ldx;
+      const T* __restrict__ xq = X + (live ? col : 0);
+      V acc0 = zero_vec<T>(), acc1 = zero_vec<T>();
+      int64_t e = e0;
+      for (; e + CHUNK <= e1; e += CHUNK) {
+        const int c = idx[e + mine];
+        T v = val[e + mine];
+        if constexpr (SHIFT) v -= shift[c];
+        bcast_steps<T, 0>(c, v, xq, ldx, acc0, acc1);
+      }
+      for (e += slot; e < e1; e += SLOTS) {
+        const int32_t ca = idx[e];
+        T va = val[e];
+        if constexpr (SHIFT) va -= shift[ca];
+        const V xa = *reinterpret_cast<const V*>(xq + (int64_t)ca * ldx);
+        fma_vec<T>(acc0, va, xa);
+      }
+      add_vec<T>(acc0, acc1);
+#pragma unroll
+      for (int off = LPR; off < WAVE; off <<= 1) add_vec<T>(acc0, shfl_xor_vec<T>(acc0, off));
+      if (slot == 0 && live) {
+        T* __restrict__ y = Y + r * (int64_t)ldy + col;
+        if (vec_store && col + VEC <= ncols) {
+          V out = acc0;
+          if (cvec) {
+            const V cv = *reinterpret_cast<const V*>(cvec + col);
+            if constexpr (VEC == 4) { out.x -= cv.x; out.y -= cv.y; out.z -= cv.z; out.w -= cv.w; }
+            else { out.x -= cv.x; out.y -= cv.y; }
+          }
+          *reinterpret_cast<V*>(y) = out;
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i)
+            if (col + i < ncols) y[i] = vec_get<T>(acc0, i) - (cvec ? cvec[col + i] : (T)0);
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int LPR>
 void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, int ncols, const T* cvec, hipStream_t s,
                       const T* shift = nullptr) {
@@ -130,6 +224,18 @@ void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, i
   int64_t blocks = (A.rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
+  static const bool per_entry = getenv("SAPCA_ROWGATHER_PER_ENTRY") != nullptr;   // (experiments: the kernel without the DPP feed)
+  if constexpr (LPR >= 16) {
+    if (!per_entry) {
+      if (shift)
+        hipLaunchKernelGGL((spmm_rowbcast_kernel<T, LPR, true>), dim3((unsigned)blocks), dim3(256), 0, s, A.ptr, A.idx, A.val,
+                           A.rows, X, ldx, Y, ldy, ncols, cvec, vec_store, shift);
+      else
+        hipLaunchKernelGGL((spmm_rowbcast_kernel<T, LPR, false>), dim3((unsigned)blocks), dim3(256), 0, s, A.ptr, A.idx, A.val,
+                           A.rows, X, ldx, Y, ldy, ncols, cvec, vec_store, shift);
+      return;
+    }
+  }
   if (shift)
     hipLaunchKernelGGL((spmm_rowgather_kernel<T, LPR, true>), dim3((unsigned)blocks), dim3(256), 0, s, A.ptr, A.idx, A.val,
                        A.rows, X, ldx, Y, ldy, ncols, cvec, vec_store, shift);

@@ -188,6 +188,49 @@ def test_spmm_edge_rows(session):
     assert np.all(z == 0) and z.shape == (3, 3)
 
 
+def _ragged_rows_csr(n, seed, dtype):
+    """rows whose lengths straddle the 16-, 32- and 64-entry chunks of the DPP-fed row kernel"""
+    lens = [0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 96, 100, 127, 128, 129, 200, 257]
+    rng = np.random.default_rng(seed)
+    rows = [np.sort(rng.choice(n, ln, replace=False)) for _ in range(12) for ln in lens]
+    ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    idx = np.concatenate(rows).astype(np.int64)
+    val = rng.standard_normal(len(idx)).astype(dtype)
+    return ptr, idx, val, len(rows)
+
+
+@pytest.mark.parametrize("dtype,l,tol", [(np.float32, 60, 2e-5), (np.float32, 110, 2e-5), (np.float64, 30, 1e-12), (np.float64, 60, 1e-12)])
+def test_row_kernel_chunk_boundaries(session, dtype, l, tol):
+    """the row kernel's two ways through a row (whole chunks fed by DPP broadcasts, the remainder entry by entry) on rows of
+    0 .. 257 entries, with panels of 16 and 32 lanes per row, with and without the centring vector"""
+    n = 700
+    ptr, idx, val, m = _ragged_rows_csr(n, 5, dtype)
+    X = synth.gaussian_panel(n, l, 3).numpy().astype(dtype)
+    mu = np.random.default_rng(2).standard_normal(n).astype(dtype)
+    D = mat(ptr, idx, val, m, n).toarray().astype(np.float64)
+    want = D @ X.astype(np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, m, n, X), want, atol=tol * scale)
+    want_c = (D - mu.astype(np.float64)[None, :]) @ X.astype(np.float64)
+    np.testing.assert_allclose(session.spmm(ptr, idx, val, m, n, X, mu), want_c, atol=tol * 20 * scale)
+
+
+@pytest.mark.parametrize("dtype,k,tol", [(np.float64, 30, 1e-10), (np.float64, 40, 1e-10), (np.float32, 40, 5e-5)])
+def test_masked_projection_row_kernel_with_long_rows(monkeypatch, dtype, k, tol):
+    """quirk Q3 through the row kernel with the mean folded in (value - mu[column] per stored, kept entry), rows of every
+    length around the chunk sizes, 16 and 32 lanes per panel row; against the oracle's entry loop"""
+    monkeypatch.setenv("SAPCA_Q3_ROWKERNEL", "1")
+    n = 700
+    ptr, idx, val, m = _ragged_rows_csr(n, 9, np.float64)
+    mask = synth.bernoulli_mask(n, 0.8, 3).numpy()
+    est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask)
+           .svd_method(SVDMethod.Random(8, 2, PIN.QR)).build())
+    got = est.fit_transform(mat(ptr, idx, val.astype(dtype), m, n))
+    comps, mean = est.components_(np.float64), est.mean_(np.float64)
+    want = O.transform_masked_fast(ptr, idx, val.astype(dtype).astype(np.float64), m, n, comps, mean, True, mask)
+    np.testing.assert_allclose(got, want, atol=tol * max(1.0, float(np.abs(want).max())))
+
+
 # ------------------------------------------------------------------ normaliser (R10)
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 5e-6)])
 def test_normalizer_qr_orthonormal_same_span(session, dtype, tol):
