@@ -1354,16 +1354,35 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 // Exclusive scans of one or two int64 arrays of count + 1 elements (the last input element is ignored; the last output is
 // the total) by ONE workgroup, plus the maximum of the first array: the tables here have 1e4 .. 1e6 elements, and one
 // launch replaces six of the library's (histogram / lookback / scan kernels for each of reduce and scan).
+// PER > 0: a thread's elements (at most PER) are loaded together and kept in registers -- one round trip to memory instead
+// of one per element, which is what the kernel's time is at these sizes; PER = 0: any count, element by element.
+template <int PER, bool HAS_B>
 __global__ void __launch_bounds__(1024)
 small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t count, int64_t* __restrict__ out_max_total) {
   __shared__ int64_t wsum[2][16], wmax[16];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int64_t per = (count + 1023) / 1024, lo = min(count, (int64_t)tid * per), hi = min(count, lo + per);
   int64_t sa = 0, sb = 0, mx = 0;
-  for (int64_t i = lo; i < hi; ++i) {
-    sa += a[i];
-    mx = max(mx, a[i]);
-    if (b) sb += b[i];
+  constexpr int NR = PER > 0 ? PER : 1;
+  int64_t ra_[NR], rb_[HAS_B ? NR : 1];
+  if constexpr (PER > 0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      ra_[u] = lo + u < hi ? a[lo + u] : 0;
+      if constexpr (HAS_B) rb_[u] = lo + u < hi ? b[lo + u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      sa += ra_[u];
+      mx = max(mx, ra_[u]);
+      if constexpr (HAS_B) sb += rb_[u];
+    }
+  } else {
+    for (int64_t i = lo; i < hi; ++i) {
+      sa += a[i];
+      mx = max(mx, a[i]);
+      if (b) sb += b[i];
+    }
   }
   // exclusive scan of the 1024 per-thread sums: inside a wave by shuffles, across the 16 waves through LDS
   int64_t ia = sa, ib = sb;
@@ -1378,6 +1397,7 @@ small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t coun
   if (lane == 0) wmax[wave] = mx;
   __syncthreads();
   int64_t ra = ia - sa, rb = ib - sb, ta = 0, tb = 0, m = 0;
+#pragma unroll 2
   for (int w = 0; w < 16; ++w) {
     if (w < wave) { ra += wsum[0][w]; rb += wsum[1][w]; }
     ta += wsum[0][w];
@@ -1389,16 +1409,36 @@ small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t coun
     if (b) b[count] = tb;
     if (out_max_total) { out_max_total[0] = m; out_max_total[1] = ta; }
   }
-  for (int64_t i = lo; i < hi; ++i) {
-    const int64_t x = a[i];
-    a[i] = ra;
-    ra += x;
-    if (b) {
-      const int64_t y = b[i];
-      b[i] = rb;
-      rb += y;
+  if constexpr (PER > 0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (lo + u < hi) {
+        a[lo + u] = ra;
+        if constexpr (HAS_B) b[lo + u] = rb;
+      }
+      ra += ra_[u];
+      if constexpr (HAS_B) rb += rb_[u];
+    }
+  } else {
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t x = a[i];
+      a[i] = ra;
+      ra += x;
+      if (b) {
+        const int64_t y = b[i];
+        b[i] = rb;
+        rb += y;
+      }
     }
   }
+}
+
+void launch_small_scan(int64_t* a, int64_t* b, int64_t count, int64_t* out_max_total, hipStream_t s) {
+  const int64_t per = (count + 1023) / 1024;
+  if (b && per <= 8) hipLaunchKernelGGL((small_scan_kernel<8, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
+  else if (b && per <= 16) hipLaunchKernelGGL((small_scan_kernel<16, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
+  else if (!b && per <= 24) hipLaunchKernelGGL((small_scan_kernel<24, false>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
+  else hipLaunchKernelGGL((small_scan_kernel<0, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
 }
 
 // ---- A^T's format straight from A through per-chunk buckets (no transposed CSR, no sort) -----------------------
@@ -1900,7 +1940,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     // maximum chunk size (staging capacity check) and the exclusive scans of the chunk sizes (and, on the bucket route, of
     // the stored-entry counts) in one launch
     int64_t* d_max = buf.misc.as<int64_t>(8);
-    hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, d_chunk, d_raw, nchunks, d_max);
+    launch_small_scan(d_chunk, d_raw, nchunks, d_max, s);
     int64_t host[2] = {0, 0};
     SAPCA_HIP(hipMemcpyAsync(host, d_max, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));  // blk goes out of scope; sizes needed on the host
@@ -2054,7 +2094,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), (size_t)n2 * 2, hist_attr);
   hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3(ATD_HIST_THREADS), (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
-  hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(1024), 0, s, at_ptr, (int64_t*)nullptr, n, (int64_t*)nullptr);
+  launch_small_scan(at_ptr, nullptr, n, nullptr, s);
   SAPCA_HIP(hipGetLastError());
   CsrView<float> At;
   At.rows = n; At.cols = m; At.nnz = A.nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr;
