@@ -120,7 +120,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     }
   }
   const bool from_at = getenv("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
-  const bool at_tile_major = sizeof(T) == 4 && tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
+  const bool at_tile_major = tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
+  const int tiled_ldp_words = tiled_ldp * (int)sizeof(T) / 4;   // panel row in 4-byte words: what the tile arithmetic counts in
 
   // mask index maps (sparse_masked/mod.rs:264-271 and the HashMap of :462-466)
   h.cols_to_use.clear();
@@ -298,7 +299,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
     int32_t* cat_idx = h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* cat_val = h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    k::transpose_csr(view(h.a_used), cat_ptr, cat_idx, cat_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp) : 0,
+    k::transpose_csr(view(h.a_used), cat_ptr, cat_idx, cat_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp_words) : 0,
                      nullptr);
     h.at_used = {n_used, m, nnz_used, cat_ptr, cat_idx, cat_val};
     if (!from_upload) {
@@ -311,6 +312,19 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     masked_compact = true;
   }
 
+  // (f64, or f32 off the bucket route: A's format is built on the side stream from this thread once the transposition is
+  // queued; the side stream forks HERE, so the two run side by side on the GPU)
+  const bool a_aside_late = !a_built_aside && tiled_ldp != 0 && !masked && !serial;
+  if (a_aside_late) {
+    if (!h.stream2) {
+      SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
+      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
+      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
+    }
+    SAPCA_HIP(hipEventRecord(h.ev_fork, s));               // A is ready on the main stream at this point
+    SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
+  }
+
   if (!at_direct && !masked_direct && !masked_compact) {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
@@ -319,20 +333,12 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     // rows of A^T grouped by the interleaved tile of the A row they came from: its format fill streams
     // unmasked: the statistics and the format builder read the sort's packed rows directly and the
     // unpack pass into (at_idx, at_val) is skipped (done lazily below if the row kernel has to take over)
-    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp) : 0,
+    k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp_words) : 0,
                      (at_tile_major && !masked && getenv("SAPCA_AT_UNPACK") == nullptr) ? &at_packed : nullptr);
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
   }
 
-  // (f64, or the serial switch: A's format on the side stream, driven from this thread after the transposition is queued)
-  if (!a_built_aside && tiled_ldp != 0 && !masked && !serial) {
-    if (!h.stream2) {
-      SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
-      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
-      SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
-    }
-    SAPCA_HIP(hipEventRecord(h.ev_fork, s));               // A is ready on the main stream at this point...
-    SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
+  if (a_aside_late) {
     h.tiled_a = TiledOp();
     if constexpr (sizeof(T) == 4) ok_a_aside = k::build_tiled(A, false, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
     else ok_a_aside = k::build_tiled(A, tiled_ldp, h.tiled_a, h.tb_a, h.stream2);
@@ -450,7 +456,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     if (tiled_ldp != 0 && n_used > 0) {
       Scope sc(h, C_PREPARE);
       if (!a_built_aside) ok_a_aside = k::build_tiled(view(h.a_used), tiled_ldp, h.tiled_a, h.tb_a, s);
-      bool ok_at = k::build_tiled(view(h.at_used), tiled_ldp, h.tiled_at, h.tb_at, s);
+      bool ok_at = k::build_tiled(view(h.at_used), tiled_ldp, h.tiled_at, h.tb_at, s, at_tile_major);
       join_aside();
       const bool ok_a = ok_a_aside;
       ok_at = ok_at && ok_a;

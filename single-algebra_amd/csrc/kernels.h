@@ -96,7 +96,7 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                  bool seg_ready = false);   // buf.seg already holds the per-row tile index (at_stats_index)
 // The same format with f64 values for panels of 64 f64 columns (512-byte rows: the tile geometry of the
 // 128-float panels); built from a CSR in natural row order by the direct fill.
-bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s);
+bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s, bool rows_tile_major = false);
 // The format of A^T (op: A.cols x A.rows) straight from A, without a transposed CSR: a histogram per (tile of A rows,
 // column), a scatter of A's entries into per-chunk buckets, one workgroup per chunk for the format.  Byte-identical to
 // build_tiled on the tile-major transposition.  at_ptr (A.cols + 1) receives A^T's row offsets, stats (2 * A.cols, may

@@ -144,6 +144,24 @@ __global__ void pack_rows64_kernel(const int64_t* __restrict__ ptr, const int32_
     }
   }
 }
+// the same with A's rows visited in tile-major order (pack_rows_permuted_kernel): every transposed row comes out grouped by tile
+template <typename K>
+__global__ void pack_rows64_permuted_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ val,
+                                            int64_t rows, int nct, const int64_t* __restrict__ pptr, K* __restrict__ keys,
+                                            RowVal64* __restrict__ packed) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+    const int64_t d0 = pptr[tile_major_rank(r, rows, nct)] - e0;
+    for (int64_t e = e0 + lane; e < e1; e += WAVE) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(val[e]);
+      packed[d0 + e] = RowVal64{(uint32_t)r, (uint32_t)b, (uint32_t)(b >> 32)};
+      keys[d0 + e] = (K)idx[e];
+    }
+  }
+}
 __global__ void unpack_rows64_kernel(const RowVal64* __restrict__ packed, int64_t count, int32_t* __restrict__ t_idx,
                                      double* __restrict__ t_val) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,13 +500,38 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
         SAPCA_HIP(rocprim::radix_sort_pairs(nullptr, sb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const RowVal64*)nullptr,
                                             (RowVal64*)nullptr, (size_t)nnz, 0u, (unsigned)bits, s));
       const size_t a4 = (size_t)round_up(nnz * 4, 256), a12 = (size_t)round_up(nnz * 12, 256);
-      char* base = static_cast<char*>(scratch.ensure(2 * a4 + 2 * a12 + sb + 256));
+      const bool permuted = tile_major_nct > 1;
+      size_t scan_bytes = 0;
+      if (permuted)
+        SAPCA_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
+                                          (size_t)A.rows + 1, rocprim::plus<int64_t>(), s));
+      const size_t a_pptr = permuted ? (size_t)round_up((A.rows + 1) * 8, 256) : 0;
+      char* base = static_cast<char*>(scratch.ensure(2 * a4 + 2 * a12 + a_pptr + std::max(sb, scan_bytes) + 256));
       uint32_t* keys_out = reinterpret_cast<uint32_t*>(base);
-      uint32_t* keys_in = reinterpret_cast<uint32_t*>(base + a4);      // (16-bit keys only)
+      uint32_t* keys_in = reinterpret_cast<uint32_t*>(base + a4);      // (16-bit keys, or the keys in tile-major row order)
       RowVal64* packed = reinterpret_cast<RowVal64*>(base + 2 * a4);
       RowVal64* packed_out = reinterpret_cast<RowVal64*>(base + 2 * a4 + a12);
-      void* tmp = base + 2 * a4 + 2 * a12;
-      if (k16) {
+      int64_t* pptr = reinterpret_cast<int64_t*>(base + 2 * a4 + 2 * a12);
+      void* tmp = base + 2 * a4 + 2 * a12 + a_pptr;
+      if (permuted) {
+        hipLaunchKernelGGL(permuted_len_kernel, dim3(grid_for(A.rows, 256, 1 << 30)), dim3(256), 0, s, A.ptr, A.rows, tile_major_nct, pptr);
+        SAPCA_HIP(rocprim::exclusive_scan(tmp, scan_bytes, pptr, pptr, (int64_t)0, (size_t)A.rows + 1, rocprim::plus<int64_t>(), s));
+      }
+      if (permuted && k16) {
+        uint16_t* k_in = reinterpret_cast<uint16_t*>(keys_in);
+        uint16_t* k_out = reinterpret_cast<uint16_t*>(keys_out);
+        hipLaunchKernelGGL((pack_rows64_permuted_kernel<uint16_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,
+                           reinterpret_cast<const double*>(A.val), A.rows, tile_major_nct, pptr, k_in, packed);
+        SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, k_in, k_out, packed, packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+        hipLaunchKernelGGL((lower_bound_kernel<uint16_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, k_out, nnz,
+                           A.cols, t_ptr);
+      } else if (permuted) {
+        hipLaunchKernelGGL((pack_rows64_permuted_kernel<uint32_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,
+                           reinterpret_cast<const double*>(A.val), A.rows, tile_major_nct, pptr, keys_in, packed);
+        SAPCA_HIP(rocprim::radix_sort_pairs(tmp, sb, keys_in, keys_out, packed, packed_out, (size_t)nnz, 0u, (unsigned)bits, s));
+        hipLaunchKernelGGL((lower_bound_kernel<uint32_t>), dim3(grid_for(A.cols + 1, 256, 1 << 30)), dim3(256), 0, s, keys_out,
+                           nnz, A.cols, t_ptr);
+      } else if (k16) {
         uint16_t* k_in = reinterpret_cast<uint16_t*>(keys_in);
         uint16_t* k_out = reinterpret_cast<uint16_t*>(keys_out);
         hipLaunchKernelGGL((pack_rows64_kernel<uint16_t>), dim3(grid_for(A.rows * WAVE, 256, 4096)), dim3(256), 0, s, A.ptr, A.idx,

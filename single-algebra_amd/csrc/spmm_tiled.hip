@@ -439,8 +439,10 @@ tile_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
   }
 }
 
-// one block per (row block, column tile), one thread per quad: steps of every quad (= its longest row segment), entry
-// offset of every wave, chunk size
+// one block per (row block, group of QC_TILES column tiles), one thread per quad: steps of every quad (= its longest row
+// segment), entry offset of every wave, chunk size
+constexpr int QC_TILES = 8;   // tiles per workgroup of quad_count_kernel: a thread reads its rows' 9 consecutive segment bounds (one or two lines)
+                              // instead of one line per (row, tile) -- a table with a 4 KiB row pitch (A^T of C2 in f64) went at 1.6 ms
 __global__ void __launch_bounds__(Q_BLOCK_QUADS)
 quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm,
                   int nct, uint16_t* __restrict__ steps, uint32_t* __restrict__ quad_off, uint32_t* __restrict__ wave_off,
@@ -448,52 +450,68 @@ quad_count_kernel(const int32_t* __restrict__ seg, const int32_t* __restrict__ b
                   int64_t* __restrict__ raw_size = nullptr) {
   __shared__ uint32_t scan[Q_BLOCK_QUADS];
   __shared__ uint32_t wave_total[Q_BLOCK_QUADS / WAVE], raw_part[Q_BLOCK_QUADS / WAVE];
-  const int rb = blockIdx.x / nct, ct = blockIdx.x % nct;
+  const int groups = (nct + QC_TILES - 1) / QC_TILES;
+  const int rb = blockIdx.x / groups, ct0 = (blockIdx.x % groups) * QC_TILES;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
   const int q = threadIdx.x, lane = q & (WAVE - 1);
-  int longest = 0, raw = 0;
+  int len[4][QC_TILES];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int lr = 4 * q + g;
-    if (lr < nrows) {
-      const int64_t r = perm ? (int64_t)perm[row0 + lr] : (int64_t)row0 + lr;   // slot -> row (rows sorted by length)
+    const bool have = lr < nrows;
+    const int64_t r = have ? (perm ? (int64_t)perm[row0 + lr] : (int64_t)row0 + lr) : 0;   // slot -> row (rows sorted by length)
+    if (cnt16) {
       // (the bucket builder of A^T counts entries per (tile, row) instead of indexing a transposed CSR)
-      const int len = cnt16 ? (int)cnt16[(int64_t)ct * cnt_stride + r] : seg[r * (nct + 1) + ct + 1] - seg[r * (nct + 1) + ct];
-      longest = max(longest, len);
-      raw += len;
+#pragma unroll
+      for (int j = 0; j < QC_TILES; ++j) len[g][j] = (have && ct0 + j < nct) ? (int)cnt16[(int64_t)(ct0 + j) * cnt_stride + r] : 0;
+    } else {
+      int bound[QC_TILES + 1];
+#pragma unroll
+      for (int j = 0; j <= QC_TILES; ++j) bound[j] = (have && ct0 + j <= nct) ? seg[r * (nct + 1) + ct0 + j] : 0;
+#pragma unroll
+      for (int j = 0; j < QC_TILES; ++j) len[g][j] = (have && ct0 + j < nct) ? bound[j + 1] - bound[j] : 0;
     }
   }
-  const int qmax = q_steps(longest);
-  const uint32_t padded = (uint32_t)qmax * 4u;
-  steps[(int64_t)blockIdx.x * Q_BLOCK_QUADS + q] = (uint16_t)qmax;
-  // inclusive scan of the padded quad sizes over the block: inside each wave by shuffles, the wave totals through LDS
-  uint32_t inc = padded;
 #pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    const uint32_t y = __shfl_up(inc, off);
-    if (lane >= off) inc += y;
-  }
+  for (int j = 0; j < QC_TILES; ++j) {
+    const int ct = ct0 + j;
+    if (ct >= nct) break;
+    const int64_t chunk = (int64_t)rb * nct + ct;
+    const int longest = max(max(len[0][j], len[1][j]), max(len[2][j], len[3][j]));
+    int raw = len[0][j] + len[1][j] + len[2][j] + len[3][j];
+    const int qmax = q_steps(longest);
+    const uint32_t padded = (uint32_t)qmax * 4u;
+    steps[chunk * Q_BLOCK_QUADS + q] = (uint16_t)qmax;
+    // inclusive scan of the padded quad sizes over the block: inside each wave by shuffles, the wave totals through LDS
+    uint32_t inc = padded;
 #pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) raw += __shfl_xor(raw, off);
-  if (lane == WAVE - 1) wave_total[q / WAVE] = inc;
-  if (lane == 0) raw_part[q / WAVE] = (uint32_t)raw;
-  __syncthreads();
-  for (int w = 0; w < q / WAVE; ++w) inc += wave_total[w];
-  scan[q] = inc;
-  __syncthreads();
-  // [row block][quad][tile]: the builder reads one quad's offsets in all tiles contiguously
-  if (quad_off && q < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + ct] = inc - padded;   // (the bucket route rebuilds them from `steps`)
-  if (q < QWAVES) {
-    const int first_quad = q_first(q, nquads);
-    wave_off[(int64_t)blockIdx.x * QWAVES + q] = first_quad > 0 ? scan[first_quad - 1] : 0u;
-  }
-  if (q == Q_BLOCK_QUADS - 1) {
-    chunk_size[blockIdx.x] = inc;
-    if (raw_size) {
-      uint32_t total = 0;
-      for (int w = 0; w < Q_BLOCK_QUADS / WAVE; ++w) total += raw_part[w];
-      raw_size[blockIdx.x] = total;
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const uint32_t y = __shfl_up(inc, off);
+      if (lane >= off) inc += y;
+    }
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) raw += __shfl_xor(raw, off);
+    __syncthreads();   // (the previous tile's readers are done)
+    if (lane == WAVE - 1) wave_total[q / WAVE] = inc;
+    if (lane == 0) raw_part[q / WAVE] = (uint32_t)raw;
+    __syncthreads();
+    for (int w = 0; w < q / WAVE; ++w) inc += wave_total[w];
+    scan[q] = inc;
+    __syncthreads();
+    // [row block][quad][tile]: the builder reads one quad's offsets in all tiles contiguously
+    if (quad_off && q < nquads) quad_off[((int64_t)rb * Q_BLOCK_QUADS + q) * nct + ct] = inc - padded;   // (the bucket route rebuilds them from `steps`)
+    if (q < QWAVES) {
+      const int first_quad = q_first(q, nquads);
+      wave_off[chunk * QWAVES + q] = first_quad > 0 ? scan[first_quad - 1] : 0u;
+    }
+    if (q == Q_BLOCK_QUADS - 1) {
+      chunk_size[chunk] = inc;
+      if (raw_size) {
+        uint32_t total = 0;
+        for (int w = 0; w < Q_BLOCK_QUADS / WAVE; ++w) total += raw_part[w];
+        raw_size[chunk] = total;
+      }
     }
   }
 }
@@ -783,12 +801,14 @@ natural_quad_slots_kernel(const int64_t* __restrict__ ptr, int64_t rows, unsigne
 // SEG_LDS: the quad's four rows of seg are staged in LDS (few tiles: the table is small and the
 // workgroups stay many per CU); otherwise every lane reads its row's bounds from global memory one
 // tile step ahead (many tiles: a [4][tiles + 1] table would leave one or two workgroups per CU).
-template <bool SEG_LDS>
+template <bool SEG_LDS, typename VT = float>
 __global__ void __launch_bounds__(256)
-quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const VT* __restrict__ val,
                       const uint64_t* __restrict__ packed, const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
                       const uint32_t* __restrict__ perm, int nct, float inv_nct, int ldp_bytes,
-                      const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off, Ent* __restrict__ ent) {
+                      const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
+                      typename EntOf<VT>::type* __restrict__ ent) {
+  typedef typename EntOf<VT>::type Ent;   // (f64: 16-byte entries; the packed rows are an f32 route)
   extern __shared__ int32_t sg_lds[];   // [4][nct + 1] the quad's rows of seg
   const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
@@ -837,14 +857,19 @@ quad_fill_runs_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict
     int qmax = max(len, __shfl_xor(len, 1));
     qmax = q_steps(max(qmax, __shfl_xor(qmax, 2)));
     for (int k = k0; k < qmax; k += 16) {
-      Ent x{0u, 0.f};
+      Ent x{};
       if (k < len) {
         const int64_t e = base + s0 + k;
         int c;
-        if (packed) {
-          const uint64_t pv = packed[e];
-          c = (int)(pv >> 32);
-          x.val = __uint_as_float((uint32_t)pv);
+        if constexpr (sizeof(VT) == 4) {
+          if (packed) {
+            const uint64_t pv = packed[e];
+            c = (int)(pv >> 32);
+            x.val = __uint_as_float((uint32_t)pv);
+          } else {
+            c = idx[e];
+            x.val = val[e];
+          }
         } else {
           c = idx[e];
           x.val = val[e];
@@ -1354,18 +1379,19 @@ void launch_tiled(const TiledOp& op, const float* X, float* out, int ldo, int nc
 // Exclusive scans of one or two int64 arrays of count + 1 elements (the last input element is ignored; the last output is
 // the total) by ONE workgroup, plus the maximum of the first array: the tables here have 1e4 .. 1e6 elements, and one
 // launch replaces six of the library's (histogram / lookback / scan kernels for each of reduce and scan).
-// PER > 0: a thread's elements (at most PER) are loaded together and kept in registers -- one round trip to memory instead
-// of one per element, which is what the kernel's time is at these sizes; PER = 0: any count, element by element.
+// Rounds of 1024 x PER elements: a thread loads its PER consecutive elements of the round together and keeps them in
+// registers -- one round trip to memory per round instead of one per element, which is what the kernel's time is at
+// these sizes; the running totals carry from round to round.
 template <int PER, bool HAS_B>
 __global__ void __launch_bounds__(1024)
 small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t count, int64_t* __restrict__ out_max_total) {
   __shared__ int64_t wsum[2][16], wmax[16];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-  const int64_t per = (count + 1023) / 1024, lo = min(count, (int64_t)tid * per), hi = min(count, lo + per);
-  int64_t sa = 0, sb = 0, mx = 0;
-  constexpr int NR = PER > 0 ? PER : 1;
-  int64_t ra_[NR], rb_[HAS_B ? NR : 1];
-  if constexpr (PER > 0) {
+  int64_t carry_a = 0, carry_b = 0, m = 0;
+  for (int64_t base = 0; base < count; base += 1024 * PER) {
+    const int64_t lo = min(count, base + (int64_t)tid * PER), hi = min(count, lo + PER);
+    int64_t sa = 0, sb = 0, mx = 0;
+    int64_t ra_[PER], rb_[HAS_B ? PER : 1];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       ra_[u] = lo + u < hi ? a[lo + u] : 0;
@@ -1377,39 +1403,29 @@ small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t coun
       mx = max(mx, ra_[u]);
       if constexpr (HAS_B) sb += rb_[u];
     }
-  } else {
-    for (int64_t i = lo; i < hi; ++i) {
-      sa += a[i];
-      mx = max(mx, a[i]);
-      if (b) sb += b[i];
+    // exclusive scan of the 1024 per-thread sums: inside a wave by shuffles, across the 16 waves through LDS
+    int64_t ia = sa, ib = sb;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const int64_t ya = __shfl_up(ia, off), yb = __shfl_up(ib, off);
+      if (lane >= off) { ia += ya; ib += yb; }
     }
-  }
-  // exclusive scan of the 1024 per-thread sums: inside a wave by shuffles, across the 16 waves through LDS
-  int64_t ia = sa, ib = sb;
 #pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    const int64_t ya = __shfl_up(ia, off), yb = __shfl_up(ib, off);
-    if (lane >= off) { ia += ya; ib += yb; }
-  }
-#pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-  if (lane == WAVE - 1) { wsum[0][wave] = ia; wsum[1][wave] = ib; }
-  if (lane == 0) wmax[wave] = mx;
-  __syncthreads();
-  int64_t ra = ia - sa, rb = ib - sb, ta = 0, tb = 0, m = 0;
+    for (int off = WAVE / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    __syncthreads();   // (the previous round's readers of wsum are done)
+    if (lane == WAVE - 1) { wsum[0][wave] = ia; wsum[1][wave] = ib; }
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    int64_t ra = carry_a + ia - sa, rb = carry_b + ib - sb, ta = 0, tb = 0;
 #pragma unroll 2
-  for (int w = 0; w < 16; ++w) {
-    if (w < wave) { ra += wsum[0][w]; rb += wsum[1][w]; }
-    ta += wsum[0][w];
-    tb += wsum[1][w];
-    m = max(m, wmax[w]);
-  }
-  if (tid == 0) {
-    a[count] = ta;
-    if (b) b[count] = tb;
-    if (out_max_total) { out_max_total[0] = m; out_max_total[1] = ta; }
-  }
-  if constexpr (PER > 0) {
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) { ra += wsum[0][w]; rb += wsum[1][w]; }
+      ta += wsum[0][w];
+      tb += wsum[1][w];
+      m = max(m, wmax[w]);
+    }
+    carry_a += ta;
+    carry_b += tb;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       if (lo + u < hi) {
@@ -1419,26 +1435,19 @@ small_scan_kernel(int64_t* __restrict__ a, int64_t* __restrict__ b, int64_t coun
       ra += ra_[u];
       if constexpr (HAS_B) rb += rb_[u];
     }
-  } else {
-    for (int64_t i = lo; i < hi; ++i) {
-      const int64_t x = a[i];
-      a[i] = ra;
-      ra += x;
-      if (b) {
-        const int64_t y = b[i];
-        b[i] = rb;
-        rb += y;
-      }
-    }
+  }
+  if (tid == 0) {
+    a[count] = carry_a;
+    if (HAS_B && b) b[count] = carry_b;
+    if (out_max_total) { out_max_total[0] = m; out_max_total[1] = carry_a; }
   }
 }
 
 void launch_small_scan(int64_t* a, int64_t* b, int64_t count, int64_t* out_max_total, hipStream_t s) {
   const int64_t per = (count + 1023) / 1024;
   if (b && per <= 8) hipLaunchKernelGGL((small_scan_kernel<8, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
-  else if (b && per <= 16) hipLaunchKernelGGL((small_scan_kernel<16, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
-  else if (!b && per <= 24) hipLaunchKernelGGL((small_scan_kernel<24, false>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
-  else hipLaunchKernelGGL((small_scan_kernel<0, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
+  else if (b) hipLaunchKernelGGL((small_scan_kernel<16, true>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
+  else hipLaunchKernelGGL((small_scan_kernel<24, false>), dim3(1), dim3(1024), 0, s, a, b, count, out_max_total);
 }
 
 // ---- A^T's format straight from A through per-chunk buckets (no transposed CSR, no sort) -----------------------
@@ -1766,7 +1775,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   const int ldp = ldp_elems * (int)sizeof(VT) / 4;
   SAPCA_CHECK(ldp == 64 || ldp == 128, SAPCA_ERR_ARG, "tiled sweep: panel rows must be 256 or 512 bytes");
   op = TiledOp();
-  if (!f32 && (transposed || rows_tile_major || packed_rows)) return false;
+  if (!f32 && (transposed || packed_rows)) return false;
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
   // the operator is S, or S^T built straight from S (quad format only)
   const int64_t op_rows = transposed ? S.cols : S.rows, op_cols = transposed ? S.rows : S.cols;
@@ -1926,10 +1935,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                          maskw, d_rank, reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     } else if (quad && direct) {
       d_raw = buf.rank.as<int64_t>((size_t)nchunks + 1);
-      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)(nrb * ((nct + QC_TILES - 1) / QC_TILES))), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), (uint32_t*)nullptr, d_wave_off, d_chunk, direct->cnt16, direct->n2, d_raw);
     } else if (quad)
-      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)nchunks), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
+      hipLaunchKernelGGL(quad_count_kernel, dim3((unsigned)(nrb * ((nct + QC_TILES - 1) / QC_TILES))), dim3(Q_BLOCK_QUADS), 0, s, d_seg, d_blk, d_perm, nct,
                          reinterpret_cast<uint16_t*>(d_steps), d_quad_off, d_wave_off, d_chunk);
     else if (slots == 2)
       hipLaunchKernelGGL((tiled_count_kernel<16, 2 * SAPCA_PADSTEPS>), dim3((unsigned)nchunks), dim3(BLOCK_ROWS), 0, s, d_seg, d_blk, nct,
@@ -1987,7 +1996,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // f64 entries are 16 bytes: the LDS image holds QF_CAP_MIN of them (64 KiB), two workgroups per CU
   const int qf_cap_max = f32 ? QF_CAP_MAX : QF_CAP_MIN;
   const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
-                           (double)total <= 0.85 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;
+                           (double)total <= 0.93 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;   // (a quad above the image takes the direct route inside the kernel)
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
   if ((packed_rows || direct) && !runs_fill) {
@@ -2053,7 +2062,17 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                        d_blk, nct, tc, ldp * 4, d_chunk, d_wave_off, d_ent, run_global);
   } else {
     (void)lds; (void)run_global; (void)d_rank;
-    if (staged_fill) {
+    if (runs_fill) {
+      // rows grouped by tile (the tile-major transposition): a quad's run in a tile is contiguous in its rows
+      const int seg_lds_max = getenv("SAPCA_RUNS_SEG_LDS_MAX") ? atoi(getenv("SAPCA_RUNS_SEG_LDS_MAX")) : 1024;
+      if (nct <= seg_lds_max)
+        hipLaunchKernelGGL((quad_fill_runs_kernel<true, double>), dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
+                           (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, (const uint64_t*)nullptr, d_seg, d_blk, d_perm, nct,
+                           inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+      else
+        hipLaunchKernelGGL((quad_fill_runs_kernel<false, double>), dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), 0, s, S.ptr, S.idx, S.val,
+                           (const uint64_t*)nullptr, d_seg, d_blk, d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+    } else if (staged_fill) {
       const size_t fill_lds = (size_t)qf_cap * sizeof(E) + ((size_t)5 * nct + 1) * sizeof(uint32_t);
       static LdsAttrState attr;
       ensure_dynamic_lds(reinterpret_cast<const void*>(&quad_fill_staged_kernel<double>), fill_lds, attr);
@@ -2074,8 +2093,8 @@ bool build_tiled(const CsrView<float>& S, bool transposed, int ldp, TiledOp& op,
                  bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready) {
   return build_tiled_t<float>(S, transposed, ldp, op, buf, s, rows_tile_major, packed_rows, allow_big_tile, seg_ready);
 }
-bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s) {
-  return build_tiled_t<double>(S, false, ldp, op, buf, s, false, nullptr, true, false);
+bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& buf, hipStream_t s, bool rows_tile_major) {
+  return build_tiled_t<double>(S, false, ldp, op, buf, s, rows_tile_major, nullptr, true, false);
 }
 
 bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, int64_t* at_ptr, double* stats,
