@@ -7,12 +7,12 @@ f=glob.glob("/tmp/ptl64/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 idx=[i for i,r in enumerate(rows) if "pack_rows64" in r["Kernel_Name"]]
-i0=max(0,idx[-1]-6)
+i0=max(0,idx[-1]-8)
 t0=int(rows[i0]["Start_Timestamp"])
 n=0
 for r in rows[i0:]:
     st=(int(r["Start_Timestamp"])-t0)/1e3; du=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
     name=r["Kernel_Name"].replace("sapca::k::(anonymous namespace)::","").replace("sapca::(anonymous namespace)::","").replace("void ","")[:60]
-    if st > 14000: break
+    if st > 11000: break
     if du>15: print("%9.1f us  %8.1f us  q%s  %s" % (st,du,r.get("Queue_Id","?"),name))
 PY
