@@ -887,6 +887,29 @@ def test_f64_fit_through_the_staged_sweep(golden):
     np.testing.assert_allclose(res[1], res[0], atol=1e-9 * np.abs(res[0]).max())
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_f64_staged_sweep_on_many_tiles_and_blocks(masked):
+    """f64 fits whose A^T format comes from the tile-major transposition and the run-wise fill (125 tiles, a dozen row blocks
+    of A^T, rows of A^T long enough to leave the LDS-staged fill): the row kernel's fit to f64 rounding, with and without a
+    column mask"""
+    m, n, k, p, q = 20000, 3000, 10, 6, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.04, k, seed=14, dtype=torch.float64))
+    mask = synth.bernoulli_mask(n, 0.7, 5).numpy() if masked else None
+    n_used = int(mask.sum()) if masked else n
+    om = synth.gaussian_panel(n_used, k + p, 5).numpy()
+    A = mat(ptr, idx, val, m, n)
+    res = []
+    for variant in (1, 2):
+        b = (sapca.MaskedSparsePCABuilder.new().mask(mask) if masked else sapca.SparsePCABuilder.new())
+        est = (b.n_components(k).spmm_variant(variant).collect_timings(True).svd_method(SVDMethod.Random(p, q, PIN.QR)).build().set_omega(om))
+        t = est.fit_transform(A)
+        res.append((t, est.singular_values_(np.float64), est.components_(np.float64), est.mean_(np.float64)))
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-10)
+    assert O.subspace_angle(res[1][2], res[0][2]) < 1e-9
+    np.testing.assert_allclose(res[1][3], res[0][3], atol=1e-13)
+    np.testing.assert_allclose(res[1][0], res[0][0], atol=1e-9 * np.abs(res[0][0]).max())
+
+
 def test_fit_is_the_same_with_either_sweep_kernel(golden):
     g = golden("g4_randomized_fit.npz")
     m, n, k, p, q = (int(g[x]) for x in "mnkpq")
