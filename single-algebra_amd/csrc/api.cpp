@@ -618,6 +618,12 @@ void sapca_destroy(sapca_handle h) {
     (void)hipStreamSynchronize(h->stream2);
     (void)hipStreamDestroy(h->stream2);
   }
+  if (h->stream3) {
+    (void)hipStreamSynchronize(h->stream3);
+    (void)hipStreamDestroy(h->stream3);
+  }
+  if (h->ev_kept) (void)hipEventDestroy(h->ev_kept);
+  if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_drop) (void)hipEventDestroy(h->ev_drop);

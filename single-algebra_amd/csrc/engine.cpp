@@ -188,6 +188,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   // compacted matrix then takes the bucket route to A^T's format; otherwise it is transposed into a CSR.
   const bool try_masked_direct = sizeof(T) == 4 && at_tile_major && masked_aside && n_used <= 65536 && getenv("SAPCA_AT_SORT") == nullptr;
   bool compaction_done = false;
+  bool side_stats = false;   // the masked-out columns' sums (and the host copy of all statistics) finish on stream3, behind the fit
   int32_t* drop_col = nullptr;
   T* drop_val = nullptr;
   if (masked_aside && getenv("SAPCA_MASK_TRANSPOSE_FIRST") == nullptr) {
@@ -201,22 +202,38 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
     compaction_done = true;
     if (!from_upload) {
-      // the masked-out columns' sums on the side stream, beside the transposition / the bucket route of the kept part
-      // (sum | sumsq of every column, zero where a column is kept; the kept columns' sums are scattered on top later)
-      if (!h.stream2) {
-        SAPCA_HIP(hipStreamCreateWithFlags(&h.stream2, hipStreamNonBlocking));
-        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming));
-        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming));
+      // the masked-out columns' sums on their own stream, beside the transposition / the bucket route of the kept part and
+      // A's format build (sum | sumsq of every column, zero where a column is kept).  Single-rank fits (`side_stats`) keep
+      // them in their own arrays and never wait for them on the main stream: see the statistics below.
+      if (!h.stream3) {
+        SAPCA_HIP(hipStreamCreateWithFlags(&h.stream3, hipStreamNonBlocking));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_kept, hipEventDisableTiming));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_stats, hipEventDisableTiming));
       }
       if (!h.ev_drop) SAPCA_HIP(hipEventCreateWithFlags(&h.ev_drop, hipEventDisableTiming));
+      SAPCA_HIP(hipStreamSynchronize(h.stream3));   // (idle unless an earlier fit failed half way: its buffers are reused here)
+      side_stats = !h.comm.active() && getenv("SAPCA_MASK_STATS_INLINE") == nullptr;
       double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
-      SAPCA_HIP(hipEventRecord(h.ev_drop, s));   // (the compaction synchronised: this only orders the side stream after it)
-      SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_drop, 0));
-      SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), h.stream2));
-      k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
-                        h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
-                        d_stats, d_stats + n, h.split_scratch, h.stream2);
-      SAPCA_HIP(hipEventRecord(h.ev_drop, h.stream2));
+      SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
+      if (!side_stats) {
+        SAPCA_HIP(hipEventRecord(h.ev_drop, s));   // (the compaction synchronised: this only orders the side stream after it)
+        SAPCA_HIP(hipStreamWaitEvent(h.stream3, h.ev_drop, 0));
+        k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                          h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                          d_stats, d_stats + n, h.drop_tmp, h.stream3);
+        SAPCA_HIP(hipEventRecord(h.ev_drop, h.stream3));
+      }
+      // side_stats, randomized fits: queued at the end of prepare(), behind the format builds -- they are the ones the first
+      // sweep waits for and the sort shares HBM badly with them, while the sweeps leave most of the HBM rate unused.
+      // Lanczos fits (HBM-bound steps, no formats): now, beside the transposition.
+      if (side_stats && h.opt.method != SAPCA_RANDOM) {
+        double* d_drop = h.drop_stats.as<double>((size_t)2 * n);
+        SAPCA_HIP(hipEventRecord(h.ev_drop, s));
+        SAPCA_HIP(hipStreamWaitEvent(h.stream3, h.ev_drop, 0));
+        k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                          h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                          d_drop, d_drop + n, h.drop_tmp, h.stream3);
+      }
     }
   }
   if (masked_aside || try_direct) {
@@ -282,7 +299,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         if (!from_upload) {
           // sums of every column from the pairs the compaction dropped (zero where a column is kept), then the kept
           // columns' sums from the bucket route on top; the per-column counts are only read by the unmasked projection
-          SAPCA_HIP(hipStreamWaitEvent(s, h.ev_drop, 0));   // (the dropped pairs' sums, from the side stream)
+          if (!side_stats) SAPCA_HIP(hipStreamWaitEvent(s, h.ev_drop, 0));   // (the dropped pairs' sums, from the side stream)
           k::scatter_pairs(d_part, d_part + n_used, d_sel, n_used, d_stats, d_stats + n, s);
         }
         At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = nullptr; At.idx = nullptr; At.val = nullptr;
@@ -305,7 +322,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     if (!from_upload) {
       double* d_part = h.scratch2.as<double>((size_t)2 * n_used + 2);
       k::row_sums(view(h.at_used), d_part, d_part + n_used, s);
-      SAPCA_HIP(hipStreamWaitEvent(s, h.ev_drop, 0));   // (the dropped pairs' sums, from the side stream)
+      if (!side_stats) SAPCA_HIP(hipStreamWaitEvent(s, h.ev_drop, 0));   // (the dropped pairs' sums, from the side stream)
       k::scatter_pairs(d_part, d_part + n_used, d_sel, n_used, d_stats, d_stats + n, s);
     }
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = nullptr; At.idx = nullptr; At.val = nullptr;
@@ -367,6 +384,15 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       }
       if (!at_seg_ready) k::row_sums(At, d_stats, d_stats + n, s);
       k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);
+    }
+    h.stats_on_side = false;
+    if (side_stats && !uploaded && (masked_direct || masked_compact)) {
+      // single rank, masked: the main stream holds the kept columns' sums (all the sweeps' centring reads); stream3 puts
+      // them over the dropped columns' arrays once both are there and copies the lot to the host -- the main stream
+      // never waits for the sort of the dropped pairs
+      sums[(size_t)2 * n] = (double)m;
+      h.stats_on_side = true;   // (the chain itself is queued at the end of prepare())
+      return;
     }
     h.m_local = (double)m;   // (a member: the copy may still be reading it when this function has returned)
     SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &h.m_local, sizeof(double), hipMemcpyHostToDevice, s));
@@ -470,6 +496,22 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   join_aside();   // (fits without tile-major formats)
   if (a_built_aside) SAPCA_HIP(hipStreamWaitEvent(s, h.ev_join, 0));
+
+  if (h.stats_on_side) {
+    // everything the first sweep needs is queued: now the masked-out columns' sums, the kept columns' sums over them, the
+    // copy of all statistics to the host (read at the end of fit())
+    double* d_stats = h.stats.ptr<double>();
+    double* d_drop = h.drop_stats.as<double>((size_t)2 * n);
+    SAPCA_HIP(hipEventRecord(h.ev_kept, s));
+    SAPCA_HIP(hipStreamWaitEvent(h.stream3, h.ev_kept, 0));
+    if (h.opt.method == SAPCA_RANDOM)
+      k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                        h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                        d_drop, d_drop + n, h.drop_tmp, h.stream3);
+    k::copy_selected(d_stats, d_stats + n, d_sel, n_used, d_drop, d_drop + n, h.stream3);
+    SAPCA_HIP(hipMemcpyAsync(sums, d_drop, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, h.stream3));
+    SAPCA_HIP(hipEventRecord(h.ev_stats, h.stream3));
+  }
 
   h.prep_key.ptr = A.ptr; h.prep_key.idx = A.idx; h.prep_key.val = A.val;
   h.prep_key.m = (uint64_t)m; h.prep_key.n = (uint64_t)n; h.prep_key.nnz = (uint64_t)nnz;
@@ -740,6 +782,7 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
   // allocates zeros(n_samples) there -- a length bug that is never read; n_cols zeros here).
   if (h.stats_pending) {   // (the copy was queued in prepare(); every path through the SVD engines has synchronised since)
     SAPCA_HIP(hipStreamSynchronize(s));
+    if (h.stats_on_side) SAPCA_HIP(hipEventSynchronize(h.ev_stats));   // (masked fits: the copy came from the third stream)
     finish_statistics(h);
   }
   h.mean = h.prep_mean;

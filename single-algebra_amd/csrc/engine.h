@@ -15,6 +15,12 @@ struct sapca_handle_s {
   bool own_stream = false;
   hipStream_t stream2 = nullptr;        // side stream: A's format is built beside the transposition (prepare)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_drop = nullptr;
+  // third stream: the sums of the columns a mask drops (a sort of the dropped pairs).  Only mean_ reads them, at the end of
+  // fit(): single-rank fits let that chain run beside the format builds AND the sweeps, and it copies the statistics to
+  // the host itself (ev_kept: the kept columns' sums are in place on the main stream; ev_stats: the host copy has landed)
+  hipStream_t stream3 = nullptr;
+  hipEvent_t ev_kept = nullptr, ev_stats = nullptr;
+  bool stats_on_side = false;
 
   // builder state
   std::vector<uint8_t> mask;
@@ -75,6 +81,7 @@ struct sapca_handle_s {
   hipEvent_t up_stats_done = nullptr;
   sapca::DevBuf at_ptr, at_idx, at_val;                          // A^T
   sapca::DevBuf ca_ptr, ca_idx, ca_val, cat_ptr, cat_idx, cat_val;  // mask-compacted A, A^T
+  sapca::DevBuf drop_stats, drop_tmp;                              // their sums (sum | sumsq, full width) and the sort's work space
   sapca::DevBuf drop_col, drop_val;                                // the entries the compaction dropped, as (column, value) pairs
   sapca::DevBuf scratch, scratch2;
   sapca::DevBuf panel_x, panel_y, panel_w;

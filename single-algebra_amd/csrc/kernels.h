@@ -45,6 +45,8 @@ template <typename T>
 void exact_colstats_add(const int64_t* ptr, const int32_t* idx, const T* val, int64_t r_lo, int64_t r_hi, int64_t e_lo, int64_t e_hi,
                         int64_t n, void* work, hipStream_t s);
 template <typename T> void exact_colstats_finish(void* work, int64_t n, double* out, int* nonfinite_host, hipStream_t s);
+// out_a[where[j]] = a[where[j]], out_b[where[j]] = b[where[j]]   (the selected positions of two full-width arrays)
+void copy_selected(const double* a, const double* b, const int32_t* where, int64_t count, double* out_a, double* out_b, hipStream_t s);
 // out_a[where[j]] = a[j], out_b[where[j]] = b[j]   (column statistics from a compacted numbering back to the full width)
 void scatter_pairs(const double* a, const double* b, const int32_t* where, int64_t count, double* out_a, double* out_b, hipStream_t s);
 // mu[j] = T(sum[sel ? sel[j] : j] / count): the column means the sweeps centre with, from the device-side column sums

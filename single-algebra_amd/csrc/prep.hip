@@ -668,6 +668,24 @@ __global__ void scatter_pairs_kernel(const double* __restrict__ a, const double*
 }
 }  // namespace
 
+namespace {
+__global__ void copy_selected_kernel(const double* __restrict__ a, const double* __restrict__ b, const int32_t* __restrict__ where,
+                                     int64_t count, double* __restrict__ out_a, double* __restrict__ out_b) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) {
+    out_a[where[j]] = a[where[j]];
+    out_b[where[j]] = b[where[j]];
+  }
+}
+}  // namespace
+
+// out[where[j]] = in[where[j]], j < count (both arrays full width): the kept columns' sums into the dropped columns' arrays
+void copy_selected(const double* a, const double* b, const int32_t* where, int64_t count, double* out_a, double* out_b, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(copy_selected_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, where, count, out_a, out_b);
+  SAPCA_HIP(hipGetLastError());
+}
+
 void scatter_pairs(const double* a, const double* b, const int32_t* where, int64_t count, double* out_a, double* out_b, hipStream_t s) {
   if (count <= 0) return;
   hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, where, count, out_a, out_b);
