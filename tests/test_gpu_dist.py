@@ -30,20 +30,23 @@ def _worker(rank, world, port, tmpdir, method):
     try:
         torch.cuda.set_device(0)
         m, n, k, p, q = 6000, 900, 8, 8, 3
-        centred = method == "random"
+        centred = method.startswith("random")
         full = synth.gapped_csr(m, n, 0.05, k, seed=23, centred=centred, dtype=torch.float32, device="cuda")
         ptr = full[0].cpu().numpy()
         r0, r1 = sdist.shard_rows(ptr, world)[rank]
         lo, hi = int(ptr[r0]), int(ptr[r1])
         shard = sapca.DeviceCsr((full[0][r0:r1 + 1] - lo).contiguous(), full[1][lo:hi].contiguous(),
                                 full[2][lo:hi].contiguous(), (r1 - r0, n))
-        sm = sapca.SVDMethod.Random(p, q) if method == "random" else sapca.SVDMethod.Lanczos()
-        om = synth.gaussian_panel(n, k + p, 5).numpy()
-        est = sapca.SparsePCABuilder.new().n_components(k).svd_method(sm).build().set_omega(om)
+        sm = sapca.SVDMethod.Random(p, q) if method.startswith("random") else sapca.SVDMethod.Lanczos()
+        masked = method.endswith("masked")
+        mask = synth.bernoulli_mask(n, 0.7, 3).numpy() if masked else None
+        om = synth.gaussian_panel(int(mask.sum()) if masked else n, k + p, 5).numpy()
+        new = (lambda: sapca.MaskedSparsePCABuilder.new().mask(mask)) if masked else sapca.SparsePCABuilder.new
+        est = new().n_components(k).svd_method(sm).build().set_omega(om)
         assert sdist.init_comm(est, prefer="torch", stage_through_host=True) == "torch"
         t = est.fit_transform(shard)
         # single-rank reference on the full matrix, same Omega
-        ref = sapca.SparsePCABuilder.new().n_components(k).svd_method(sm).build().set_omega(om)
+        ref = new().n_components(k).svd_method(sm).build().set_omega(om)
         t_ref = ref.fit_transform(sapca.DeviceCsr(*full, (m, n)))
         np.testing.assert_allclose(est.singular_values_(np.float64), ref.singular_values_(np.float64), rtol=2e-5)
         np.testing.assert_allclose(est.mean_(np.float64), ref.mean_(np.float64), atol=1e-6)
@@ -103,7 +106,7 @@ def test_two_ranks_on_either_side_of_the_staged_sweep_floor(tmp_path):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-@pytest.mark.parametrize("method", ["random", "lanczos"])
+@pytest.mark.parametrize("method", ["random", "lanczos", "random_masked"])   # (masked: the masked-out columns' sums cross the all-reduce too)
 def test_two_rank_row_sharded_fit(tmp_path, method):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), method), nprocs=world, join=True)
