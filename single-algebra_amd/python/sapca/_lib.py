@@ -106,3 +106,16 @@ def check(handle, status):
     if status != OK:
         msg = load().sapca_last_error(handle)
         raise SapcaError(status, (msg or b"").decode() or f"sapca status {status}")
+
+
+def as_u64(a):
+    """A CSR offset / index array in the library's u64 (nalgebra_sparse `usize`) layout: int64 arrays -- what scipy holds for
+    large matrices -- are reinterpreted in place (a negative entry reads as an index the library refuses), anything else
+    is converted (a copy)."""
+    import numpy as np
+    a = np.asarray(a)
+    if a.dtype == np.uint64 and a.flags.c_contiguous:
+        return a
+    if a.dtype == np.int64 and a.flags.c_contiguous:
+        return a.view(np.uint64)
+    return np.ascontiguousarray(a, dtype=np.uint64)

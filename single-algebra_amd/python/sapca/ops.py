@@ -8,6 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
+from ._lib import as_u64
 
 _SUF = {np.dtype(np.float32): ("f32", C.c_float), np.dtype(np.float64): ("f64", C.c_double)}
 
@@ -37,8 +38,8 @@ class Session:
             pass
 
     def _csr_args(self, indptr, indices, data, m, n):
-        ro = np.ascontiguousarray(indptr, dtype=np.uint64)
-        ci = np.ascontiguousarray(indices, dtype=np.uint64)
+        ro = as_u64(indptr)
+        ci = as_u64(indices)
         va = np.ascontiguousarray(data)
         suf, ct = _SUF[va.dtype]
         keep = (ro, ci, va)
@@ -162,7 +163,7 @@ Session.upload = _upload
 
 def partition_rows(indptr, nparts):
     """nnz-balanced contiguous row ranges (host-only code path of the library)."""
-    ro = np.ascontiguousarray(indptr, dtype=np.uint64)
+    ro = as_u64(indptr)
     bounds = np.zeros(nparts + 1, dtype=np.uint64)
     st = L.load().sapca_partition_rows(C.c_uint64(ro.size - 1), _p(ro, C.c_uint64), C.c_uint32(nparts), _p(bounds, C.c_uint64))
     if st != L.OK:

@@ -22,6 +22,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib as L
+from ._lib import as_u64
 
 
 class PowerIterationNormalizer(enum.IntEnum):
@@ -175,8 +176,8 @@ class _Estimator:
         suf, ct = _SUF[dt]
         m, n = x.shape
         self._mask_check(n)
-        ro = np.ascontiguousarray(x.indptr, dtype=np.uint64)     # nalgebra_sparse usize layout
-        ci = np.ascontiguousarray(x.indices, dtype=np.uint64)
+        ro = as_u64(x.indptr)     # nalgebra_sparse usize layout
+        ci = as_u64(x.indices)
         va = np.ascontiguousarray(x.data)
         args = [self._h, C.c_uint64(m), C.c_uint64(n), C.c_uint64(va.size), _np_ptr(ro, C.c_uint64),
                 _np_ptr(ci, C.c_uint64), _np_ptr(va, ct)]
