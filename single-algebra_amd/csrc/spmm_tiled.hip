@@ -207,6 +207,7 @@ __device__ __forceinline__ void steps_batch(typename Lane<VPL>::V& acc, const ch
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));   // output rows are only element-aligned (ldo = k)
 constexpr int np_tile(int threads) { return TILE_BYTES / (threads * 16); }
 constexpr int np_stage(int threads) { return (STAGE_BYTES + threads * 16 - 1) / (threads * 16); }
 
@@ -1211,7 +1212,7 @@ spmm_quad_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restric
         if (col + 3 < ncols) {
           v4f o = acc[j][v];
           o.x -= cv[0]; o.y -= cv[1]; o.z -= cv[2]; o.w -= cv[3];
-          *reinterpret_cast<v4f*>(y) = o;
+          *reinterpret_cast<v4f_a4*>(y) = o;
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -1240,6 +1241,7 @@ void launch_quad(const TiledOp& op, const float* X, int ldx, float* out, int ldo
 // 80 KiB tile, 4 rows per lane group, 256 rows per workgroup).  A lane holds the doubles 2q, 2q+1 and
 // 32+2q, 32+2q+1 of its row (two ds_read_b128); entries are 16 bytes {offset, pad, f64 value}.
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 
 template <int U>
@@ -1344,7 +1346,7 @@ spmm_quad_f64_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __res
         if (col + 1 < ncols) {
           v2d o = acc[j][v];
           o.x -= cv[0]; o.y -= cv[1];
-          *reinterpret_cast<v2d*>(y) = o;
+          *reinterpret_cast<v2d_a8*>(y) = o;
         } else if (col < ncols) {
           y[0] = acc[j][v].x - cv[0];
         }
