@@ -76,7 +76,15 @@ void jacobi_svd(const std::vector<double>& A, int l, std::vector<double>& U, std
 // ---- symmetric eigenproblem of the l x l Gram (f32 randomized path) ----------------------------------
 // Householder reduction to tridiagonal form (EISPACK tred2 structure): on return `a` holds the orthogonal
 // Q with A = Q T Q^T (row-major), d the diagonal and e the sub-diagonal of T (e[i] couples i-1 and i).
-static void householder_tridiag(double* a, int n, double* d, double* e) {
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("arch=haswell", "default")))
+#endif
+static void householder_tridiag(double* a, int n, double* d, double* e, double* work) {
+  // The active block a[0..l][0..l] is kept SYMMETRIC in both triangles, so that A u and the rank-2 update walk rows
+  // (contiguous, vectorised) instead of columns; tred2 proper works on the lower triangle alone.  work: 2 n doubles
+  // (no containers in here: the function is compiled once per target, and library inlines do not cross that line).
+  double* u = work;
+  double* q = work + n;
   for (int i = n - 1; i >= 1; --i) {
     const int l = i - 1;
     double hh = 0, scale = 0;
@@ -95,22 +103,25 @@ static void householder_tridiag(double* a, int n, double* d, double* e) {
         e[i] = scale * g;
         hh -= f * g;
         ai[l] = f - g;
+        for (int k = 0; k <= l; ++k) u[k] = ai[k];
+        // p = A u / hh (rows of the symmetric block), f = u . p
         f = 0;
         for (int j = 0; j <= l; ++j) {
-          double* aj = a + (size_t)j * n;
-          aj[i] = ai[j] / hh;
-          g = 0;
-          for (int k = 0; k <= j; ++k) g += aj[k] * ai[k];
-          for (int k = j + 1; k <= l; ++k) g += a[(size_t)k * n + j] * ai[k];
-          e[j] = g / hh;
-          f += e[j] * ai[j];
+          const double* aj = a + (size_t)j * n;
+          double acc = 0;
+          for (int k = 0; k <= l; ++k) acc += aj[k] * u[k];
+          e[j] = acc / hh;
+          f += e[j] * u[j];
         }
         const double hk = f / (hh + hh);
+        for (int j = 0; j <= l; ++j) q[j] = e[j] - hk * u[j];
+        // A <- A - u q^T - q u^T on the whole block; column i keeps u / hh for the accumulation of Q below
         for (int j = 0; j <= l; ++j) {
           double* aj = a + (size_t)j * n;
-          f = ai[j];
-          e[j] = g = e[j] - hk * f;
-          for (int k = 0; k <= j; ++k) aj[k] -= f * e[k] + g * ai[k];
+          const double uj = u[j], qj = q[j];
+          for (int k = 0; k <= l; ++k) aj[k] -= uj * q[k] + qj * u[k];
+          aj[i] = uj / hh;
+          e[j] = qj;
         }
       }
     } else {
@@ -124,10 +135,18 @@ static void householder_tridiag(double* a, int n, double* d, double* e) {
     const int l = i - 1;
     double* ai = a + (size_t)i * n;
     if (d[i] != 0.0) {
-      for (int j = 0; j <= l; ++j) {
-        double g = 0;
-        for (int k = 0; k <= l; ++k) g += ai[k] * a[(size_t)k * n + j];
-        for (int k = 0; k <= l; ++k) a[(size_t)k * n + j] -= g * a[(size_t)k * n + i];
+      // Q(0..l, 0..l) <- Q - (u / hh) (u^T Q): g = u^T Q as a sum of rows, then one row update each
+      double* g = q;
+      for (int j = 0; j <= l; ++j) g[j] = 0;
+      for (int k = 0; k <= l; ++k) {
+        const double* ak = a + (size_t)k * n;
+        const double uk = ai[k];
+        for (int j = 0; j <= l; ++j) g[j] += uk * ak[j];
+      }
+      for (int k = 0; k <= l; ++k) {
+        double* ak = a + (size_t)k * n;
+        const double w = ak[i];
+        for (int j = 0; j <= l; ++j) ak[j] -= g[j] * w;
       }
     }
     d[i] = ai[i];
@@ -160,7 +179,8 @@ static bool ql_implicit_rows(double* d, double* e, int n, double* zt) {
         int i;
         for (i = m - 1; i >= l; --i) {
           double f = s * e[i], b = c * e[i];
-          r = std::hypot(f, g);
+          r = std::sqrt(f * f + g * g);
+          if (!(r >= 1e-150 && r <= 1e150)) r = std::hypot(f, g);   // (squares out of range: the careful form)
           e[i + 1] = r;
           if (r == 0.0) {
             d[i + 1] -= p;
@@ -197,7 +217,10 @@ bool sym_eigh_desc(const std::vector<double>& A, int n, std::vector<double>& w, 
   Vt.assign((size_t)n * n, 0.0);
   if (n <= 0) return true;
   std::vector<double> a(A.begin(), A.begin() + (size_t)n * n), d((size_t)n), e((size_t)n), zt((size_t)n * n);
-  householder_tridiag(a.data(), n, d.data(), e.data());
+  for (int j = 0; j < n; ++j)
+    for (int k = j + 1; k < n; ++k) a[(size_t)j * n + k] = a[(size_t)k * n + j];   // the lower triangle is the matrix
+  std::vector<double> work((size_t)2 * n);
+  householder_tridiag(a.data(), n, d.data(), e.data(), work.data());
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < n; ++k) zt[(size_t)i * n + k] = a[(size_t)k * n + i];   // rows of zt = columns of Q
   if (!ql_implicit_rows(d.data(), e.data(), n, zt.data())) return false;
