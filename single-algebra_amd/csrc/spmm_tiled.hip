@@ -1465,21 +1465,27 @@ constexpr int ATD_THREADS = 1024;
 constexpr int ATD_MASK_WORDS = 10;        // 320 rows of a tile
 
 constexpr int ATD_HIST_THREADS = 512;   // (a tile per workgroup; eight waves: three or four tiles per CU at once, no second round at C2)
+constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave one workgroup per CU: sixteen waves then (C5: 100 KB)
 
-__global__ void __launch_bounds__(ATD_HIST_THREADS)
+__global__ void __launch_bounds__(ATD_HIST_THREADS_WIDE)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
                 uint16_t* __restrict__ cnt16) {
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
   const int t = blockIdx.x;
   const int nw = (int)(n2 / 2);
-  for (int i = threadIdx.x; i < nw; i += ATD_HIST_THREADS) atd_h32[i] = 0u;
+  const int nthreads = (int)blockDim.x, nwaves = nthreads / WAVE;
+  for (int i = threadIdx.x; i < nw; i += nthreads) atd_h32[i] = 0u;
   __syncthreads();
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  for (int i = wave; i < tc; i += ATD_HIST_THREADS / WAVE) {
-    const int64_t r = (int64_t)t + (int64_t)i * nct;
+  // (the next row's offsets are fetched while this row's indices are in flight: a row is one batch at C5's 500 entries)
+  int64_t r = (int64_t)t + (int64_t)wave * nct;
+  int64_t e0 = (wave < tc && r < m) ? ptr[r] : 0, e1 = (wave < tc && r < m) ? ptr[r + 1] : 0;
+  for (int i = wave; i < tc; i += nwaves) {
     if (r >= m) break;
-    const int64_t e1 = ptr[r + 1];
-    for (int64_t eb = ptr[r] + lane; eb < e1; eb += 8 * WAVE) {   // eight loads in flight per lane
+    const int64_t rn = r + (int64_t)nwaves * nct;
+    const bool more = i + nwaves < tc && rn < m;
+    const int64_t n0 = more ? ptr[rn] : 0, n1 = more ? ptr[rn + 1] : 0;
+    for (int64_t eb = e0 + lane; eb < e1; eb += 8 * WAVE) {   // eight loads in flight per lane
       int c[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) c[u] = eb + u * WAVE < e1 ? idx[eb + u * WAVE] : -1;
@@ -1487,10 +1493,13 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
       for (int u = 0; u < 8; ++u)
         if (c[u] >= 0) atomicAdd(&atd_h32[c[u] >> 1], 1u << (16 * (c[u] & 1)));   // (at most 320 rows per tile: no carry into the neighbour)
     }
+    r = rn;
+    e0 = n0;
+    e1 = n1;
   }
   __syncthreads();
   uint32_t* out = reinterpret_cast<uint32_t*>(cnt16 + (int64_t)t * n2);
-  for (int i = threadIdx.x; i < nw; i += ATD_HIST_THREADS) out[i] = atd_h32[i];
+  for (int i = threadIdx.x; i < nw; i += nthreads) out[i] = atd_h32[i];
 }
 
 // len[c] = entries of column c (summed over the tiles); the caller scans it into A^T's row offsets.
@@ -2113,7 +2122,8 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   uint16_t* cnt16 = buf.seg.as<uint16_t>((size_t)nct * n2);   // (takes the place of the per-row tile index of the other routes)
   static LdsAttrState hist_attr;
   ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), (size_t)n2 * 2, hist_attr);
-  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3(ATD_HIST_THREADS), (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
+  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 64 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),
+                     (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
   launch_small_scan(at_ptr, nullptr, n, nullptr, s);
   SAPCA_HIP(hipGetLastError());
