@@ -7,9 +7,12 @@
 
 A "step" is one fit_transform of the hot path over a device-resident CSR (inputs already in
 HBM when the timed region starts).  At N=1 the workload is BASELINE.json configs[1] (C2:
-200k x 20k f32, ~97 % sparse, randomized SVD k=50, p=10, q=4, QR normalizer).  For N>1 every
-rank holds a 200k-row shard of the (N*200k) x 20k matrix (weak scaling), rows range-partitioned,
-panels all-reduced over RCCL inside the library.
+200k x 20k f32, ~97 % sparse, randomized SVD k=50, p=10, q=4, QR normalizer); the line also
+carries a 3-step `c4_1gpu` record (BASELINE configs[3]'s 1M x 30k matrix on the one GPU: the
+shape north_star's roofline target is quoted on).  For N>1 the default is BASELINE configs[3]
+STRONG-scaled: the 1M x 30k matrix split by rows over the ranks (`"scaling": "strong"`), rows
+range-partitioned, panels all-reduced over RCCL inside the library; `--scaling weak` gives
+every rank a 200k-row shard of the (N*200k) x 20k matrix instead.
 
 One JSON line on rank 0: metric/value = whole-job algorithmic GB/s of fit_transform (SURVEY.md
 §8d formula / wall-clock), ms_per_step = fit_transform wall-clock, `roofline` for the dominant
@@ -67,9 +70,21 @@ def cpu_baseline(name, n, density, k, p, q, seed, gen_device="cpu"):
     orc.transform_sparse(ptr, idx, val, ms, n, comps, mean, True)   # closed form of the Q2 loop (the literal loop is O(m*k*nnz))
     dt = time.perf_counter() - t0
     _, total = alg_bytes(ms, n, len(val), k + p, k, q)
-    return {"value": total / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "kind": "port",
+    return {"value": total / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{ms} x {n} row sample of the workload ({len(val)} stored entries), fit + closed-form transform, "
                       f"{dt:.2f} s; restatement of the reference algorithm, not the reference binary"}
+
+
+def cpu_model():
+    """Model name of the host CPU the baseline ran on (SURVEY.md 8d asks for model + core count)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def bench_lanczos(args, rank, local_rank, world, dev):
@@ -210,49 +225,16 @@ def e2e_host_ms(args, m, n, density, k, p, q, dev, local_rank):
     return best, parts
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank holds the workload's rows (default, c2 shards); strong: the workload's rows are split "
-                         "over the ranks (default workload c4: 1M x 30k, BASELINE.json configs[3])")
-    ap.add_argument("--spmm-variant", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the measured copy rate, the host-path run and the C1 comparison")
-    args = ap.parse_args()
-    if args.workload is None:
-        args.workload = "c4" if args.scaling == "strong" else "c2"
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ndev = torch.cuda.device_count()
-    shared = world > ndev                     # fewer GPUs than ranks (a one-GPU box rehearsing the launcher): ranks share
-    local_rank = local_rank % max(ndev, 1)    # devices and the collectives go through gloo on host copies
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-    rdev = torch.device("cpu") if shared else dev     # where this script's own small reductions live
-
+def run_randomized(workload, scaling, steps, warmup, rank, world, local_rank, dev, rdev, shared, spmm_variant):
+    """`warmup` untimed + `steps` timed fit_transforms of one randomized-SVD workload, rows range-partitioned over the
+    ranks (weak: every rank holds the workload's row count; strong: the workload's rows are split).  The timed region is
+    bracketed by a barrier + torch.cuda.synchronize() on both sides; the returned wall time is the MAX over ranks."""
     import sapca
+    import torch.distributed as dist
     from sapca import synth
-    m_cfg, n, density, k, p, q = WORKLOADS[args.workload]
+    m_cfg, n, density, k, p, q = WORKLOADS[workload]
     seed = 42
-    if args.workload == "c3":
-        return bench_lanczos(args, rank, local_rank, world, dev)
-    if args.scaling == "strong":
+    if scaling == "strong":
         # rows of the one m_cfg-row matrix, split evenly: the generator's rows are identically distributed, so equal row
         # counts are entry-balanced to 0.1 % (sapca_partition_rows does the same from the row offsets of a host matrix)
         r0, r1 = m_cfg * rank // world, m_cfg * (rank + 1) // world
@@ -261,20 +243,11 @@ def main():
         r0, r1 = rank * m_cfg, (rank + 1) * m_cfg
         m_total = m_cfg * world
     m = r1 - r0
-    # the host-path measurement first, on a process that has done nothing else yet (what a caller's process looks like;
-    # measured after the timed loop the same upload took 33-49 ms instead of 21: host memory placement, not the library)
-    e2e = None
-    if world == 1 and not args.no_extras and args.workload in ("c2", "small"):
-        try:
-            e2e = e2e_host_ms(args, m, n, density, k, p, q, dev, local_rank)
-        except Exception as e:   # never lose the line to an extra
-            e2e = repr(e)
-        torch.cuda.empty_cache()
     ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=seed, row_start=r0, dtype=torch.float32, device=dev)
     x = sapca.DeviceCsr(ptr, idx, val, (m, n))
     nnz = x.nnz
     pca = (sapca.SparsePCABuilder.new().n_components(k).random_seed(42).device(local_rank).collect_timings(True)
-           .spmm_variant(args.spmm_variant)
+           .spmm_variant(spmm_variant)
            .svd_method(sapca.SVDMethod.Random(p, q, sapca.PowerIterationNormalizer.QR)).build())
     transport = "none"
     if world > 1:
@@ -289,18 +262,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = pca.fit_transform(x)
     barrier()
     t0 = time.perf_counter()
     sweep_ms = []
     stage = {}
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = pca.fit_transform(x)
         t = pca.timings()
         sweep_ms += list(t.spmm_sweep_ms[: t.n_spmm]) + list(t.spmmt_sweep_ms[: t.n_spmmt])
         for f in ("prepare_ms", "stats_ms", "spmm_ms", "spmmt_ms", "ortho_ms", "small_svd_ms", "transform_ms", "comm_ms", "fit_total_ms"):
-            stage[f] = stage.get(f, 0.0) + getattr(t, f) / args.steps
+            stage[f] = stage.get(f, 0.0) + getattr(t, f) / steps
     barrier()
     dt = time.perf_counter() - t0
     avg_sweep_ms = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
@@ -319,38 +292,131 @@ def main():
     else:
         nnz_total = float(nnz)
     assert out.shape == (m, k) and bool(torch.isfinite(out).all())
-
     l = k + p
     sweep_bytes, _ = alg_bytes(m, n, nnz, l, k, q)                      # per rank (one launch)
     _, total_bytes = alg_bytes(m_total, n, nnz_total, l, k, q)          # whole job
-    ms_per_step = dt / args.steps * 1e3
-    achieved = sweep_bytes / (avg_sweep_ms * 1e-3) / 1e9
-    traffic = None
+    t = pca.timings()
+    res = {"workload": workload, "scaling": scaling, "m_total": m_total, "m": m, "n": n, "density": density, "k": k, "p": p, "q": q,
+           "seed": seed, "nnz": nnz, "nnz_total": nnz_total, "dt": dt, "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "value": total_bytes / (dt / steps) / 1e9, "stage": stage, "transport": transport, "sweep_ms": sweep_ms,
+           "avg_sweep_ms": avg_sweep_ms, "per_rank_sweep": per_rank_sweep, "sweep_bytes": sweep_bytes,
+           "achieved": sweep_bytes / (avg_sweep_ms * 1e-3) / 1e9, "sweep_kernel": int(t.sweep_kernel),
+           "slots": 0.5 * (t.sweep_slots_a + t.sweep_slots_at)}
+    del out, x, ptr, idx, val, pca
+    torch.cuda.empty_cache()
+    return res
+
+
+def sub_record(r):
+    """A secondary workload in the line: what was run, its step time and the sweep's place against the HBM roofline."""
+    return {"workload": f"{r['workload']}: {r['m_total']} x {r['n']} CSR f32, density {r['density']}, k={r['k']} p={r['p']} q={r['q']} QR, "
+                        f"{r['scaling']} scaling, inputs resident in HBM",
+            "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "GB/s", "nnz": int(r["nnz_total"]),
+            "sweep_ms": r["avg_sweep_ms"], "stage_ms": r["stage"], "collectives": r["transport"],
+            "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["achieved"] / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": r["sweep_bytes"], "avg_launch_ms": r["avg_sweep_ms"],
+                         "launches_timed": len(r["sweep_ms"])}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong: the workload's rows are split over the ranks (the default for --gpus N > 1, workload c4: 1M x 30k, "
+                         "BASELINE.json configs[3]); weak: every rank holds the workload's rows (the default at one GPU, workload c2: "
+                         "BASELINE.json configs[1])")
+    ap.add_argument("--spmm-variant", type=int, default=0)
+    ap.add_argument("--weak-c2", action="store_true",
+                    help="N > 1: after the strong-scaled C4 headline also run 3 steps of weak-scaled C2 shards (a `weak_c2` record)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the measured copy rate, the host-path run, the C1 comparison and the secondary workloads "
+                         "(c4_1gpu at one GPU)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if args.scaling is None:
+        # the driver runs `bench.py --gpus N`: N > 1 must measure BASELINE.json configs[3] (1M x 30k split by rows over
+        # the ranks: north_star's ">= 6x at 8 GPUs"), one GPU configs[1]
+        args.scaling = "strong" if (world > 1 and args.workload in (None, "c4", "c5")) else "weak"
+    if args.workload is None:
+        args.workload = "c4" if args.scaling == "strong" else "c2"
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    shared = world > ndev                     # fewer GPUs than ranks (a one-GPU box rehearsing the launcher): ranks share
+    local_rank = local_rank % max(ndev, 1)    # devices and the collectives go through gloo on host copies
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    rdev = torch.device("cpu") if shared else dev     # where this script's own small reductions live
+
+    if args.workload == "c3":
+        return bench_lanczos(args, rank, local_rank, world, dev)
+    m_cfg, n, density, k, p, q = WORKLOADS[args.workload]
+    # the host-path measurement first, on a process that has done nothing else yet (what a caller's process looks like;
+    # measured after the timed loop the same upload took 33-49 ms instead of 21: host memory placement, not the library)
+    e2e = None
+    if world == 1 and not args.no_extras and args.workload in ("c2", "small"):
+        try:
+            e2e = e2e_host_ms(args, m_cfg, n, density, k, p, q, dev, local_rank)
+        except Exception as e:   # never lose the line to an extra
+            e2e = repr(e)
+        torch.cuda.empty_cache()
+    r = run_randomized(args.workload, args.scaling, args.steps, args.warmup, rank, world, local_rank, dev, rdev, shared, args.spmm_variant)
+    # secondary workloads (every rank takes part): BASELINE configs[3] on one GPU beside the C2 headline (north_star's
+    # roofline target is quoted on 1M x 30k at one GPU); the weak-scaled C2 shards beside the strong-scaled C4 headline
+    extra = {}
+    if not args.no_extras:
+        try:
+            if world == 1 and args.workload == "c2":
+                extra["c4_1gpu"] = sub_record(run_randomized("c4", "strong", 3, 1, rank, world, local_rank, dev, rdev, shared, args.spmm_variant))
+            elif world > 1 and args.workload == "c4" and args.scaling == "strong" and args.weak_c2:
+                extra["weak_c2"] = sub_record(run_randomized("c2", "weak", 3, 1, rank, world, local_rank, dev, rdev, shared, args.spmm_variant))
+        except Exception as e:   # never lose the line to an extra (on every rank the same way: the workload is collective)
+            extra["secondary_error"] = repr(e)
+
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath)).get(args.workload, {})
+            traffic = tj.get("hbm_bytes_per_launch")
+            if traffic is not None:
+                # not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (tools/pmc_traffic.sh)
+                traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command; not measured in this run)"
         except Exception:
             traffic = None
     if rank == 0:
-        t = pca.timings()
         kernel_names = {0: "spmm_rowgather_kernel", 1: "spmm_quad_kernel (entries staged in LDS)", 2: "spmm_dq_kernel (DPP-fed quad sweep)"}
-        slots = 0.5 * (t.sweep_slots_a + t.sweep_slots_at)
+        slots = r["slots"]
         lds_bytes = slots * 4 * 64                                      # one 256-byte panel row gathered from LDS per entry slot
+        avg_sweep_ms, achieved = r["avg_sweep_ms"], r["achieved"]
         line = {
-            "metric": "sparse_pca_fit_transform_algorithmic_throughput", "value": total_bytes / (dt / args.steps) / 1e9,
-            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "metric": "sparse_pca_fit_transform_algorithmic_throughput", "value": r["value"],
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {m_total} x {n} CSR f32, density {density}, gapped generator seed {seed}, "
+            "config": {"workload": f"{args.workload}: {r['m_total']} x {n} CSR f32, density {density}, gapped generator seed {r['seed']}, "
                                    f"SparsePCA fit_transform, SVDMethod::Random k={k} p={p} q={q} QR, rows range-partitioned "
-                                   f"over {world} GPU(s) ({args.scaling} scaling), inputs resident in HBM, collectives: {transport}",
-                       "nnz": int(nnz_total), "rows_per_gpu": m, "sweeps_per_fit": 2 * q + 2, "stage_ms": stage,
-                       "collectives": transport, "comm_ms": stage.get("comm_ms", 0.0), "sweep_ms_per_rank": per_rank_sweep},
+                                   f"over {world} GPU(s) ({args.scaling} scaling), inputs resident in HBM, collectives: {r['transport']}",
+                       "nnz": int(r["nnz_total"]), "rows_per_gpu": r["m"], "sweeps_per_fit": 2 * q + 2, "stage_ms": r["stage"],
+                       "collectives": r["transport"], "comm_ms": r["stage"].get("comm_ms", 0.0), "sweep_ms_per_rank": r["per_rank_sweep"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"{kernel_names.get(int(t.sweep_kernel), '?')}: spmm sweep (A*X and A^T*Y launches, HIP events on the library stream)",
-                         "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_ms,
-                         "launches_timed": len(sweep_ms)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": f"{kernel_names.get(r['sweep_kernel'], '?')}: spmm sweep (A*X and A^T*Y launches, HIP events on the library stream)",
+                         "algorithmic_bytes_per_launch": r["sweep_bytes"], "avg_launch_ms": avg_sweep_ms,
+                         "launches_timed": len(r["sweep_ms"])},
         }
         if slots > 0:
             # what binds the sweep in practice: every entry slot gathers a 256-byte panel row from LDS and costs four
@@ -358,9 +424,9 @@ def main():
             line["roofline"]["secondary"] = {"bound": "lds", "achieved": lds_bytes / (avg_sweep_ms * 1e-3) / 1e9, "peak": 150000.0,
                                              "unit": "GB/s", "frac": lds_bytes / (avg_sweep_ms * 1e-3) / 1e9 / 150000.0,
                                              "lds_gather_bytes_per_launch": lds_bytes, "entry_slots_per_launch": slots,
-                                             "stored_entries_per_launch": int(nnz)}
+                                             "stored_entries_per_launch": int(r["nnz"])}
+        line.update(extra)
         if not args.no_extras:
-            del out
             peak_meas = measured_copy_gbs(dev)
             line["roofline"]["peak_measured"] = peak_meas
             line["roofline"]["frac_of_measured"] = achieved / peak_meas
@@ -370,7 +436,7 @@ def main():
             line["e2e_host_ms"] = None
             line["e2e_host_error"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, n, density, k, p, q, seed, dev)
+            line["cpu_baseline"] = cpu_baseline(args.workload, n, density, k, p, q, r["seed"], dev)
             if not args.no_extras:
                 line["cpu_baseline_c1"] = c1_comparison(dev, local_rank)
         print(json.dumps(line))
