@@ -266,6 +266,12 @@ sapca_status sapca_normalize_csr_device_f64(sapca_handle h, uint64_t m, uint64_t
  * in place on the DEVICE value array.                                                           */
 sapca_status sapca_log1p_csr_device_f32(sapca_handle h, uint64_t nnz, float* values);
 sapca_status sapca_log1p_csr_device_f64(sapca_handle h, uint64_t nnz, double* values);
+/* d_values of sapca_upload_csr_* is writable: a caller that edits the uploaded values with its own
+ * kernel (anything but the two entry points above) says so here BEFORE the next fit, so that the
+ * column statistics gathered during the upload and any cached preparation are dropped and the
+ * fit re-derives mean_ / the total variance from the values as they are now.  The reference has
+ * no counterpart (a &CsrMatrix is immutable while borrowed, sparse/mod.rs:102).                  */
+sapca_status sapca_upload_values_changed(sapca_handle h);
 /* The per-row (direction 0) or per-column (direction 1) statistics of the MatrixSum /
  * MatrixNonZero / MatrixMinMax traits in one call on a device-resident CSR: sum_row|col
  * (csr.rs:259-392), sum_row|col_squared (:558-630), nonzero_row|col (:23-134, stored entries),

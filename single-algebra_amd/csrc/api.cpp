@@ -808,6 +808,13 @@ sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint3
   return SAPCA_OK;
 }
 
+sapca_status sapca_upload_values_changed(sapca_handle h) {
+  return guarded(h, [&] {
+    h->prep_key.valid = false;
+    h->up_stats.valid = false;
+  });
+}
+
 int sapca_comm_rccl_available(void) { return sapca::Comm::rccl_available() ? 1 : 0; }
 
 sapca_status sapca_comm_unique_id(uint8_t id[128]) {

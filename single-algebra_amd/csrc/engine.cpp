@@ -93,6 +93,12 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   if (masked && (int64_t)h.mask.size() != n)  // sparse_masked/mod.rs:258-262
     throw Error(SAPCA_ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!");
   h.prep_key.valid = false;
+  // A masked fit that failed after its prepare() (n_components check, SVD failure, no Lanczos convergence) leaves its
+  // statistics chain queued on the third stream: that chain sorts in at_* and copies into the pinned statistics, which
+  // every kind of fit reuses from here on.  Idle in the normal case.
+  if (h.stream3) SAPCA_HIP(hipStreamSynchronize(h.stream3));
+  h.stats_pending = false;
+  h.stats_on_side = false;
 
   // LDS-staged sweep (f32, randomized): decided here because it fixes the order in which the transposed
   // rows are produced.  It refills an 80 KiB panel tile per (row block, column tile) chunk and only beats
@@ -211,7 +217,6 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         SAPCA_HIP(hipEventCreateWithFlags(&h.ev_stats, hipEventDisableTiming));
       }
       if (!h.ev_drop) SAPCA_HIP(hipEventCreateWithFlags(&h.ev_drop, hipEventDisableTiming));
-      SAPCA_HIP(hipStreamSynchronize(h.stream3));   // (idle unless an earlier fit failed half way: its buffers are reused here)
       side_stats = !h.comm.active() && getenv("SAPCA_MASK_STATS_INLINE") == nullptr;
       double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
       SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
@@ -536,6 +541,16 @@ void Engine<T>::finish_statistics(H& h) {
     if (masked) for (uint64_t j : h.cols_to_use) h.prep_total_var += var_of((int64_t)j);
     else for (int64_t j = 0; j < n; ++j) h.prep_total_var += var_of(j);
   }
+  // Q3 through two sweeps (A'W - P diag(mu) W, transform()) subtracts two f32 sums that cancel where stored values sit
+  // close to their column's mean, i.e. in a well-filled column of small spread: (sum a)^2 / (m sum a^2) -> 1.  The
+  // reference subtracts entry by entry (sparse_masked/mod.rs:488-494) and keeps those digits; above 1/4 the projection
+  // takes the row kernel, which does the same.
+  h.q3_cancels = false;
+  if (h.opt.center && masked)
+    for (uint64_t j : h.cols_to_use) {
+      const double sj = sums[(size_t)j], qj = sums[(size_t)n + j];
+      if (qj > 0 && sj * sj > 0.25 * mg * qj) { h.q3_cancels = true; break; }
+    }
   h.stats_pending = false;
 }
 
@@ -890,7 +905,7 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
         // the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (spmm_dq.hip)
-        if (center && top && h.opt.spmm_variant != 1 && getenv("SAPCA_Q3_ROWKERNEL") == nullptr) {
+        if (center && top && h.opt.spmm_variant != 1 && !h.q3_cancels && getenv("SAPCA_Q3_ROWKERNEL") == nullptr) {
           float* W2 = h.scratch2.as<float>((size_t)n_used * ldk);
           float* tmp = h.panel_y.as<float>((size_t)m * std::max(k, 1));
           done = k::q3_projection_dq(Au, *top, W, ldk, mu, W2, tmp, d_out, k, s);

@@ -57,6 +57,7 @@ struct sapca_handle_s {
   uint64_t m_global = 0;
   std::vector<double> prep_mean;  // column means of the prepared matrix (n)
   double prep_total_var = 0;
+  bool q3_cancels = false;        // a kept column is well filled and of small spread: the masked projection subtracts entry by entry
   // the column sums on the host (sum | sumsq | row count), copied asynchronously: single-rank fits read them at the end
   // of fit() instead of stalling the stream between the preparation and the first sweep
   sapca::PinnedBuf stats_host;

@@ -80,6 +80,8 @@ class ResidentCsr {
     check(ResidentAbi<T>::normalize(h_, m_, n_, nnz_, ptr_, idx_, val_, sums.data(), sums.size(), target, (int32_t)d));
   }
   void log1p_normalize() { check(ResidentAbi<T>::log1p(h_, nnz_, val_)); }
+  // values() is writable: after editing them with a kernel of your own, say so before the next fit
+  void values_changed() { check(sapca_upload_values_changed(h_)); }
   std::vector<double> sum(Direction d) const {
     std::vector<double> s(d == Direction::COLUMN ? n_ : m_);
     check(ResidentAbi<T>::stats(h_, m_, n_, nnz_, ptr_, idx_, val_, (int32_t)d, s.data(), nullptr, nullptr, nullptr, nullptr));

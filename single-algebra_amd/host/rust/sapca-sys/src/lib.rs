@@ -103,6 +103,7 @@ extern "C" {
                                           target: f64, direction: i32) -> c_int;
     pub fn sapca_log1p_csr_device_f32(h: sapca_handle, nnz: u64, values: *mut f32) -> c_int;
     pub fn sapca_log1p_csr_device_f64(h: sapca_handle, nnz: u64, values: *mut f64) -> c_int;
+    pub fn sapca_upload_values_changed(h: sapca_handle) -> c_int;
     pub fn sapca_stats_csr_device_f32(h: sapca_handle, m: u64, n: u64, nnz: u64, row_offsets: *const i64,
                                       col_indices: *const i32, values: *const f32, direction: i32, sum: *mut f64,
                                       sum_squared: *mut f64, nonzero: *mut u64, min_out: *mut f32, max_out: *mut f32) -> c_int;

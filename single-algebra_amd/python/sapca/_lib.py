@@ -55,7 +55,7 @@ _PLAIN = [
     "sapca_options_default", "sapca_abi_version", "sapca_create", "sapca_destroy", "sapca_last_error",
     "sapca_set_mask", "sapca_get_dims", "sapca_get_total_variance", "sapca_get_mask_index_maps",
     "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_rccl_available", "sapca_comm_init_rank",
-    "sapca_comm_set_callback", "sapca_comm_allreduce",
+    "sapca_comm_set_callback", "sapca_comm_allreduce", "sapca_upload_values_changed",
 ]
 EXPORTED_SYMBOLS = _PLAIN + [f"{n}_{s}" for n in _TYPED for s in ("f32", "f64")]
 

@@ -109,6 +109,11 @@ class ResidentCsr:
         L.check(self._s._h, getattr(L.load(), f"sapca_log1p_csr_device_{suf}")(self._s._h, C.c_uint64(self.nnz), C.c_void_p(self.d_val)))
         return self
 
+    def values_changed(self):
+        """the caller edited the device values itself: drop the statistics gathered at upload (sapca_upload_values_changed)"""
+        L.check(self._s._h, L.load().sapca_upload_values_changed(self._s._h))
+        return self
+
     def stats(self, direction):
         """(sum, sum_squared, nonzero, min, max) per row (ROW) or column (COLUMN): sum_row/col, sum_row/col_squared,
         nonzero_row/col, min_max_row/col of the reference (csr.rs:23-134, 259-392, 558-630, 917-1008)"""

@@ -1,8 +1,8 @@
 cd /tmp; export TMPDIR=/tmp
 SAPCA_TILED_FROM_A=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfa -o fa -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/fa.json 2>/dev/null
 python3 - <<PY
-import csv,glob,json
-d=json.loads(open("/root/repo/gpurun_out/fa.json").read().strip().splitlines()[-1])
+import csv,glob,json,os
+d=json.loads(open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/fa.json").read().strip().splitlines()[-1])
 print(d["ms_per_step"], d["config"]["stage_ms"])
 f=glob.glob("/tmp/pfa/**/*kernel_stats.csv",recursive=True)[0]
 for r in csv.DictReader(open(f)):

@@ -5,11 +5,12 @@ cd /tmp; export TMPDIR=/tmp
 tag=$1; wl=${2:-c2}
 for c in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $c | tr A-Z a-z)
-  rm -rf /tmp/pmc_$tag_$lc
+  rm -rf /tmp/pmc_${tag}_$lc
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$lc -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 - <<PY
 import csv,glob,collections,re
-f=glob.glob("/tmp/pmc_${tag}_$lc/*/*counter_collection.csv")[0]
+import os
+f=max(glob.glob("/tmp/pmc_${tag}_$lc/*/*counter_collection.csv"), key=os.path.getmtime)
 rows=[r for r in csv.DictReader(open(f)) if "spmm_dq" in r["Kernel_Name"] or "spmm_quad" in r["Kernel_Name"] or "spmm_rowgather" in r["Kernel_Name"]]
 out=open("$GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$lc.csv","w")
 w=csv.writer(out); w.writerow(["Dispatch_Id","Kernel","Grid_Size","Counter_Name","Counter_Value"])
