@@ -134,14 +134,12 @@ struct TiledOp {
   const uint32_t* wave_off = nullptr;  // [nrb*nct][8]
   const uint8_t* steps = nullptr;      // [nrb*nct][256]
   const void* ent = nullptr;           // {u32 lds byte offset, f32 value} or {u32 offset, u32 pad, f64 value}
-  // DPP-fed sweep (spmm_dq.hip): per (row block, wave, tile) {entry offset / 8, 16-step chunks}, and one byte per
-  // two steps (4 x row slot of the wave; placed at 8 * (entry offset / 64 + (chunk * 16 + wave)))
+  // DPP-fed sweep (spmm_dq.hip): per (row block, wave, tile) {entry offset / 8, 16-step chunks}
   bool dq = false;
-  const uint8_t* dq_desc = nullptr;
   const uint32_t* dq_info = nullptr;
 };
 struct TiledBuffers {
-  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens, dq_desc, dq_info;
+  DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens, dq_info;
   // the DPP-fed sweep's tables are a latency-bound kernel over the counts: it runs on this stream beside the
   // bandwidth-bound fill (fork / join events on the build's own stream)
   hipStream_t aux = nullptr;

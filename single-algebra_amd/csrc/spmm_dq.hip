@@ -1,20 +1,22 @@
 // DPP-fed quad sweep: the default f32 sparse x dense-panel sweep for panels of 64 columns (two passes for 128).
 //
-// Same operator format as spmm_tiled.hip's quad sweep (row blocks of <= 512 rows, interleaved column tiles of 320 panel
-// rows, four rows of a quad advancing in lockstep, entries {u32 tile byte offset, f32 value} stored step by step), read
-// differently.  Measured on the staged-entry kernel: per step it pays two dependent LDS round trips (entry,
-// then panel row) and ran at 3.5 cycles per entry slot per CU.  Here
+// Same operator format as spmm_tiled.hip's quad sweep (row blocks of <= 512 or 1024 rows, interleaved column tiles of 320
+// panel rows, four rows of a quad advancing in lockstep, entries {u32 tile byte offset, f32 value} stored step by step),
+// read differently.  Measured on the staged-entry kernel: per step it pays two dependent LDS round trips
+// (entry, then panel row) and ran at 3.5 cycles per entry slot per CU.  Here
 //   * entries never touch LDS: a wave loads 16 steps of its four rows with ONE coalesced 512-byte global_load_dwordx2
 //     (lane (g, i) = step i of lane group g) and step s reaches the 16 lanes of its group through DPP row_newbcast:s,
 //     folded into the address add (v_add_u32_dpp) and one v_mov_b32_dpp for the value;
 //   * the panel tile is double-buffered in the whole 160 KiB of LDS (2 x 80 KiB) and filled by LDS-DMA
 //     (global_load_lds_dwordx4) while the previous tile is being used: no register staging, no ds_write phase;
-//   * the accumulators of a wave's 32 rows sit in v[64..95] and are addressed through the VGPR index mode: which row a
-//     step belongs to is wave-uniform but not static once the entry stream is consumed in fixed 16-step chunks, so a
-//     descriptor byte per two steps (4 x row slot, built with the format) goes to M0 (s_set_gpr_idx_on).  Steps past
-//     the end of a wave's stream in its last chunk land in a trash slot.
-// tools/ubench/dpp_quad.hip measured the core at 1.55 cycles per entry slot per CU.  The main loop is inline assembly
-// (fixed registers, counted waits), written by tools/gen_spmm_dq.py into spmm_dq_gen.h; prologue and epilogue are HIP C++.
+//   * the accumulators of a wave's 64 (32) rows sit in v[56..119] (v[56..87]); the main loop exists once per row slot with
+//     the slot's registers written into its FMAs, and which slot a step belongs to is control flow: a scalar counter of
+//     the two-step groups the current quad still has in this tile, one conditional branch per group, a stub that fetches
+//     the next quad's count from the format's own `steps` table.  A wave's stream in a tile ends exactly at its last step.
+//     (Round 2 addressed the accumulators through the VGPR index mode from a descriptor byte per two steps: two more scalar
+//     instructions per group, a descriptor table, 7 % of the steps executed past stream ends into a trash slot.)
+// The main loop is inline assembly (fixed registers, counted waits), written by tools/gen_spmm_dq2.py into
+// spmm_dq2_gen.h; prologue and epilogue are HIP C++.
 //
 // Replaces: the sweeps Y = Ac Omega / Z = Ac^T Y inside single_svdlib::randomized::randomized_svd (call sites
 // /root/reference/src/dimred/pca/sparse/mod.rs:170-180, sparse_masked/mod.rs:341-351) and the projection of transform.
@@ -25,7 +27,11 @@
 #include <algorithm>
 
 #include "spmm_dq.h"
-#include "spmm_dq_gen.h"
+#ifdef DQ2_GEN_H   // experiment variants of the generated main loop (tools/dq2_variant.sh)
+#include DQ2_GEN_H
+#else
+#include "spmm_dq2_gen.h"
+#endif
 
 namespace sapca {
 namespace k {
@@ -35,8 +41,9 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int DQ_WAVES = 16, DQ_THREADS = DQ_WAVES * WAVE;
 constexpr int DQ_BLOCK_QUADS = 256;           // stride of the per-chunk quad step table (= Q_BLOCK_QUADS of spmm_tiled.hip)
+constexpr int DQ_TILE_BYTES = DQ2_TILE_BYTES;
 constexpr int DQ_LDS = 2 * DQ_TILE_BYTES;
-static_assert(DQ_ACC_BASE == 56, "the accumulator operands below are written out for row slots starting at v56");
+static_assert(DQ2_ACC_BASE == 56, "the accumulator operands below are written out for row slots starting at v56");
 
 __host__ __device__ inline int dq_first(int wave, int nquads) { return wave * nquads / DQ_WAVES; }
 
@@ -44,58 +51,37 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 
-// One wave per (row block, tile, wave of the sweep): the entry offset and chunk count of that wave's stream, and the
-// descriptor bytes (4 x row slot of every two-step group; steps past the end -> the trash slot).
+// One wave per (row block, tile, wave of the sweep): the entry offset and chunk count of that wave's stream.
 __global__ void __launch_bounds__(256)
-dq_desc_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __restrict__ chunk_off,
-               const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, int rg, uint8_t* __restrict__ desc,
-               uint32_t* __restrict__ info, int* __restrict__ max_nch, int64_t nchunks) {
+dq_info_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __restrict__ chunk_off,
+               const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, uint32_t* __restrict__ info, int64_t nchunks) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wpb = blockDim.x / WAVE, ntasks = nchunks * DQ_WAVES;
   for (int64_t task = (int64_t)blockIdx.x * wpb + threadIdx.x / WAVE; task < ntasks; task += (int64_t)gridDim.x * wpb) {
-  const int64_t cidx = task / DQ_WAVES;
-  const int wave = (int)(task % DQ_WAVES);
-  const int rb = (int)(cidx / nct), t = (int)(cidx % nct);
-  const int nrows = blk_row0[rb + 1] - blk_row0[rb];
-  const int nquads = (nrows + 3) / 4;
-  const int quad0 = dq_first(wave, nquads), my_quads = dq_first(wave + 1, nquads) - quad0;
-  const int n = lane < my_quads ? (int)steps[cidx * DQ_BLOCK_QUADS + quad0 + lane] : 0;
-  int cum = n;
+    const int64_t cidx = task / DQ_WAVES;
+    const int wave = (int)(task % DQ_WAVES);
+    const int rb = (int)(cidx / nct), t = (int)(cidx % nct);
+    const int nrows = blk_row0[rb + 1] - blk_row0[rb];
+    const int nquads = (nrows + 3) / 4;
+    const int quad0 = dq_first(wave, nquads), my_quads = dq_first(wave + 1, nquads) - quad0;
+    int n = lane < my_quads ? (int)steps[cidx * DQ_BLOCK_QUADS + quad0 + lane] : 0;   // my_quads <= 16
 #pragma unroll
-  for (int off = 1; off < 16; off <<= 1) {
-    const int y = __shfl_up(cum, off);
-    if (lane >= off) cum += y;
-  }
-  const int N = __shfl(cum, 15);   // my_quads <= 16: lanes past the last quad add nothing
-  const int64_t s = chunk_off[cidx] + (int64_t)wave_off[cidx * DQ_WAVES + wave];
-  const int nch = (N + 15) / 16;
-  if (lane == 0) {
-    uint32_t* w = info + (((int64_t)rb * DQ_WAVES + wave) * nct + t) * 2;
-    w[0] = (uint32_t)(s / 8);
-    const int tail = N - 16 * (nch - 1);                       // steps of the last chunk (1..16), even
-    w[1] = (uint32_t)nch | ((uint32_t)(nch ? (tail + 1) / 2 : 0) << 16);   // .. as two-step groups in the upper half
-    if (nch > 4096) atomicMax(max_nch, nch);
-  }
-  uint8_t* d = desc + 8 * (s / 64 + cidx * DQ_WAVES + wave);
-  int cj[16];
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) cj[jj] = __shfl(cum, jj);
-  for (int p = lane; p < nch * 8; p += WAVE) {
-    const int step = 2 * p;
-    int j = 0;
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) j += (jj < my_quads && cj[jj] <= step) ? 1 : 0;
-    d[p] = (uint8_t)(step < N ? 4 * j : 4 * rg);
-  }
+    for (int off = 1; off < 16; off <<= 1) n += __shfl_xor(n, off);
+    if (lane == 0) {
+      const int64_t s = chunk_off[cidx] + (int64_t)wave_off[cidx * DQ_WAVES + wave];
+      uint32_t* w = info + (((int64_t)rb * DQ_WAVES + wave) * nct + t) * 2;
+      w[0] = (uint32_t)(s / 8);
+      w[1] = (uint32_t)((n + 15) / 16);
+    }
   }
 }
 
-template <int RG>   // row slots per lane group: 8 (blocks of <= 512 rows) or 16 (<= 1024)
+template <int RG, bool PAT>   // row slots per lane group: 8 (blocks of <= 512 rows) or 16 (<= 1024); pattern mode (quirk Q3)
 __global__ void __launch_bounds__(DQ_THREADS)
 spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct,
-               const uint64_t* __restrict__ ent, const uint8_t* __restrict__ desc, const uint32_t* __restrict__ info,
-               int64_t panel_rows, const float* __restrict__ X, int ldx, int nsplit, int tiles_per_split,
-               float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec, int mode) {
+                const uint64_t* __restrict__ ent, const uint16_t* __restrict__ steps, const uint32_t* __restrict__ info,
+                int64_t panel_rows, const float* __restrict__ X, int ldx, int nsplit, int tiles_per_split,
+                float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
@@ -109,34 +95,50 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
   v8f a0, a1, a2, a3, a4, a5, a6, a7;   // row slots 2i, 2i+1 (RG = 8: a0..a3)
   if (ct0 < ct1) {
     const unsigned lds_base = (unsigned)(size_t)lds;
-    unsigned lb = lds_base + q * 16, eoff = q * 32 + g * 8, l8 = lane * 8, l4 = lane * 4, l128 = lane * 128, col16 = q * 16;
+    unsigned lb = lds_base + q * 16, eoff = q * 32 + g * 8, l8 = lane * 8, l2 = lane * 2, l2c = min(lane, 15) * 2, col16 = q * 16;
     unsigned rowb0 = (unsigned)(4 * (wave * 5) + g) * (unsigned)nct;
     const unsigned wdma = __builtin_amdgcn_readfirstlane(lds_base + wave * 5 * 1024);
-    const unsigned cw = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)rb * nct + ct0) * DQ_WAVES + wave));
-    unsigned long long ip = (unsigned long long)(info + (((int64_t)rb * DQ_WAVES + wave) * nct + ct0) * 2);
-    ip = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ip >> 32)) << 32) |
-         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ip);
+    const unsigned myq = __builtin_amdgcn_readfirstlane((unsigned)my_quads);
+    auto uniform64 = [](unsigned long long p) {
+      return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) << 32) |
+             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)p);
+    };
+    const unsigned long long ip = uniform64((unsigned long long)(info + (((int64_t)rb * DQ_WAVES + wave) * nct + ct0) * 2));
+    const unsigned long long stp = uniform64((unsigned long long)(steps + ((int64_t)rb * nct + ct0) * DQ_BLOCK_QUADS + quad0));
     const unsigned xlo = (unsigned)(uintptr_t)X, xhi = (unsigned)((uintptr_t)X >> 32);
     const unsigned voff = (unsigned)g * (unsigned)nct * ((unsigned)ldx * 4u) + col16;   // lane part of an LDS-DMA piece's source address
     const unsigned stride = (unsigned)ldx * 4u, prm1 = (unsigned)(panel_rows - 1), ntiles = (unsigned)(ct1 - ct0), t0 = (unsigned)ct0;
-#define DQ_INPUTS                                                                                                       \
-  [ent] "s"(ent), [desc] "s"(desc), [xlo] "s"(xlo), [xhi] "s"(xhi), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8), [l4] "v"(l4), \
-      [l128] "v"(l128), [col16] "v"(col16), [rowb0] "v"(rowb0), [nct] "s"(nct), [stride] "s"(stride), [prm1] "s"(prm1),      \
-      [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [cw] "s"(cw), [mode] "s"(mode), [voff] "v"(voff)
+#define DQ2_INPUTS                                                                                                      \
+  [ent] "s"(ent), [stp] "s"(stp), [xlo] "s"(xlo), [xhi] "s"(xhi), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8), [l2] "v"(l2), [l2c] "v"(l2c), \
+      [col16] "v"(col16), [rowb0] "v"(rowb0), [nct] "s"(nct), [stride] "s"(stride), [prm1] "s"(prm1),                     \
+      [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [myq] "s"(myq), [voff] "v"(voff)
     if constexpr (RG == 8) {
-      asm volatile(DQ_MAIN_ASM_8
-                   : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)
-                   : DQ_INPUTS
-                   : DQ_MAIN_CLOBBERS_8);
+      if constexpr (PAT)
+        asm volatile(DQ2_MAIN_ASM_8_PAT
+                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)
+                     : DQ2_INPUTS
+                     : DQ2_MAIN_CLOBBERS_8);
+      else
+        asm volatile(DQ2_MAIN_ASM_8
+                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)
+                     : DQ2_INPUTS
+                     : DQ2_MAIN_CLOBBERS_8);
       a4 = a5 = a6 = a7 = v8f(0.f);
     } else {
-      asm volatile(DQ_MAIN_ASM_16
-                   : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3), "=&{v[88:95]}"(a4),
-                     "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7)
-                   : DQ_INPUTS
-                   : DQ_MAIN_CLOBBERS_16);
+      if constexpr (PAT)
+        asm volatile(DQ2_MAIN_ASM_16_PAT
+                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3), "=&{v[88:95]}"(a4),
+                       "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7)
+                     : DQ2_INPUTS
+                     : DQ2_MAIN_CLOBBERS_16);
+      else
+        asm volatile(DQ2_MAIN_ASM_16
+                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3), "=&{v[88:95]}"(a4),
+                       "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7)
+                     : DQ2_INPUTS
+                     : DQ2_MAIN_CLOBBERS_16);
     }
-#undef DQ_INPUTS
+#undef DQ2_INPUTS
   } else {
     a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = v8f(0.f);
   }
@@ -177,22 +179,15 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   static const bool off = getenv("SAPCA_NO_DQ") != nullptr;
   if (off || !op.valid || op.elem != 4 || op.fmt != 1 || op.ldp != 64 || op.tile_bytes != DQ_TILE_BYTES) return false;
   if (op.block_rows != 512 && op.block_rows != 1024) return false;
-  const int rg = op.block_rows / 64;
   if (op.total_entries / 8 >= (int64_t)1 << 32) return false;
   const int64_t nchunks = (int64_t)op.nrb * op.nct;
-  const size_t desc_bytes = (size_t)(op.total_entries / 64 + nchunks * DQ_WAVES + 64) * 8   /* + slack: a wave reads 256 descriptor bytes per tile */;
-  uint8_t* d_desc = buf.dq_desc.as<uint8_t>(desc_bytes);
-  const size_t info_words = ((size_t)nchunks * DQ_WAVES + 64) * 2;
-  uint32_t* d_info = buf.dq_info.as<uint32_t>(info_words + 4);
-  int* d_max = reinterpret_cast<int*>(d_info + info_words);
-  SAPCA_HIP(hipMemsetAsync(d_info + (size_t)nchunks * DQ_WAVES * 2, 0, (64 * 2 + 4) * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(dq_desc_kernel, dim3((unsigned)std::min<int64_t>(nchunks * DQ_WAVES / 4 + 1, 8192)), dim3(256), 0, s, op.blk_row0, op.nct,
-                     op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps), rg, d_desc, d_info, d_max, nchunks);
+  const size_t info_words = ((size_t)nchunks * DQ_WAVES + 64) * 2;   // (+ a 64-tile window of slack: the sweep loads whole windows)
+  uint32_t* d_info = buf.dq_info.as<uint32_t>(info_words);
+  SAPCA_HIP(hipMemsetAsync(d_info + (size_t)nchunks * DQ_WAVES * 2, 0, 64 * 2 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(dq_info_kernel, dim3((unsigned)std::min<int64_t>(nchunks * DQ_WAVES / 4 + 1, 8192)), dim3(256), 0, s, op.blk_row0, op.nct,
+                     op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps), d_info, nchunks);
   SAPCA_HIP(hipGetLastError());
-  // (a wave's stream in one tile may be any length: the sweep reloads its descriptor register every 32 chunks.  The chunk
-  // count shares its table word with the tail length: 16 bits, i.e. 1M steps of one wave in one tile, cannot be reached
-  // with u16 step counts per quad and 16 quads per wave)
-  op.dq_desc = d_desc;
+  // (the chunk count of a wave's stream in one tile: at most 16 quads x 65535 steps / 16 = 65535, the 16 bits the sweep reads)
   op.dq_info = d_info;
   op.dq = true;
   return true;
@@ -203,12 +198,16 @@ bool dq_usable(const TiledOp& op, int ldx) { return op.dq && (ldx == 64 || ldx =
 template <int RG>
 static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int flags,
                         hipStream_t s) {
-  static LdsAttrState attr;
-  static const int mode = getenv("SAPCA_DQ_MODE") ? atoi(getenv("SAPCA_DQ_MODE")) & 7 : 0;   // 1: tile loop without compute (timing only)
-  ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_dq_kernel<RG>), DQ_LDS, attr);
-  hipLaunchKernelGGL(spmm_dq_kernel<RG>, dim3((unsigned)(op.nrb * op.nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm,
-                     op.nct, reinterpret_cast<const uint64_t*>(op.ent), op.dq_desc, op.dq_info, op.cols, X, ldx, op.nsplit,
-                     op.tiles_per_split, out, op.rows, ldo, ncols, cvec, mode | flags);
+  static LdsAttrState attr[2];
+  const bool pat = (flags & 8) != 0;
+  const auto launch = [&](auto kern, LdsAttrState& a) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), DQ_LDS, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(op.nrb * op.nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm, op.nct,
+                       reinterpret_cast<const uint64_t*>(op.ent), reinterpret_cast<const uint16_t*>(op.steps), op.dq_info, op.cols, X, ldx,
+                       op.nsplit, op.tiles_per_split, out, op.rows, ldo, ncols, cvec);
+  };
+  if (pat) launch(&spmm_dq_kernel<RG, true>, attr[1]);
+  else launch(&spmm_dq_kernel<RG, false>, attr[0]);
 }
 
 void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s, int flags) {

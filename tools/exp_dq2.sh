@@ -1,16 +1,15 @@
-cd /tmp; export TMPDIR=/tmp
-for mode in 0 2 4 6; do
-  rm -rf /tmp/pr_$mode
-  SAPCA_DQ_MODE=$mode timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr_$mode -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
-  echo "== mode $mode"
-  python3 - <<PY
-import csv,glob
-f=glob.glob("/tmp/pr_$mode/*/*kernel_trace.csv")
-import collections
-d=collections.defaultdict(list)
-for r in csv.DictReader(open(f[0])):
-    if "spmm_dq" in r["Kernel_Name"]:
-        d[r["Grid_Size_X"]].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6)
-for g,v in d.items(): print("  grid", g, "n", len(v), "avg ms %.3f" % (sum(v)/len(v)), "min %.3f" % min(v))
-PY
+#!/bin/bash
+# GPU box: time the C2 sweeps with every variant library under single-algebra_amd/lib/exp (+ the default build), twice
+# each, and check each variant's sweep against the golden vectors.   bash tools/exp_dq2.sh [names...]
+cd $GRAFT_REPO_ROOT
+names="$@"; [ -z "$names" ] && names=$(ls single-algebra_amd/lib/exp/ | sed 's/libsapca_//; s/\.so//')
+for rep in 1 2; do
+  python3 tools/abl_run.py 2>/dev/null | tail -1
+  for n in $names; do
+    SAPCA_LIB_PATH=$PWD/single-algebra_amd/lib/exp/libsapca_$n.so python3 tools/abl_run.py 2>/dev/null | tail -1
+  done
+done
+for n in $names; do
+  echo "== parity $n"
+  SAPCA_LIB_PATH=$PWD/single-algebra_amd/lib/exp/libsapca_$n.so timeout -k 10 200 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "g3_spmm_tiled or spmm_tiled_matches or staged_sweep_on_ragged" 2>&1 | tail -2
 done

@@ -1,0 +1,425 @@
+#!/usr/bin/env python3
+"""Emits single-algebra_amd/csrc/spmm_dq2_gen.h: the inline-asm main loop of the DPP-fed quad sweep, second formulation
+(spmm_dq.hip, spmm_dq2_kernel).
+
+Same operator format, same entry feed (one coalesced 512-byte load per 16 steps of a wave's four rows, step s broadcast to
+its 16-lane group by DPP row_newbcast:s), same LDS-DMA double-buffered panel tile as the first formulation
+(tools/gen_spmm_dq.py).  What changed is how a step finds its accumulators.  There the row slot of every two-step group
+came from a descriptor byte through the VGPR index mode: s_set_gpr_idx_on / off around the FMAs of every group (DPP
+instructions are not exempt from the destination index), a shift per group, two v_readlane per chunk, a descriptor table
+beside the format, and steps past the end of a wave's stream executed into a trash slot (7 % of all steps at C2).  Here the
+row slot is a matter of control flow:
+
+  * the main loop exists once per row slot (RG copies of the eight two-step groups of a chunk), with the slot's four
+    accumulator registers written into the FMAs;
+  * a scalar counter holds the two-step groups the current quad still has in this tile; every group ends with
+    s_sub_u32 + s_cbranch_scc1, and the branch (taken once per quad and tile) leads through a short stub that fetches the
+    next non-empty quad's count (v_readlane from a register holding the tile's sixteen counts: the format's own `steps`
+    table, no descriptors) into the same position of the next slot's copy;
+  * the stream of a (wave, tile) ends exactly where its last quad ends: nothing is executed past it;
+  * per group: 8 VALU + 2 LDS + 3 scalar instructions instead of 8 + 2 + 4, per chunk about a dozen control
+    instructions instead of thirty (no run-time wait counts: every chunk slot issues exactly one entry load, last, so
+    the entries of chunk g are complete at vmcnt(2); one shared chunk routine per entry buffer, entered and left by
+    s_setpc_b64).
+
+Chunk control is shared by all slots: BODY[s][7] jumps to the routine of the current entry buffer (S_CTL), which copies
+the buffer into the register pair the bodies read, re-issues the buffer's load three chunks ahead (this tile's, or the next
+tile's first three chunks when the two tiles are linked), issues one LDS-DMA piece of the next tile while there are any,
+starts the first two groups and returns to position 0 of the current slot's copy (S_RET).
+
+Run:  python3 tools/gen_spmm_dq2.py   (writes the header next to the kernel; the header is committed)
+"""
+import os
+import re
+import sys
+
+ACC = 56          # first accumulator register; 4 per row slot
+RG = 16           # row slots per lane group (rows per wave = 4 * RG): set per variant in main()
+TILE_B = 81920    # bytes of one LDS tile buffer (320 panel rows of 256 bytes)
+EB = [(10, 11), (12, 13), (14, 15)]
+ECUR = (16, 17)   # the chunk being executed: {LDS byte offset, value} of lane (g, i) = step i of lane group g
+VT, VLB = 18, 19
+A = [[20, 21], [22, 23]]
+B = [24, 26]
+VINFO = (28, 29)
+VA64 = 30         # v[30:31]: 64-bit source address of an LDS-DMA piece
+W = [[32, 36], [40, 44]]
+VCNT, VCNT2 = 48, 49   # two-step groups - 1 of this wave's quads in the current tile (lane j = quad j; -1: none); raw step counts of the next
+DEPTH = int(os.environ.get("DQ2_DEPTH", "2"))   # two-step groups in flight per wave (3: a third register set behind the accumulators)
+ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved with the next group's DPP instructions, reads last
+# experiment switches (environment, read when the header is generated)
+B64 = os.environ.get("DQ2_B64", "0") != "0"     # one 64-bit row_newbcast move per step ({offset, value}) + a plain add, instead of add_dpp + mov_dpp
+FMAC = os.environ.get("DQ2_FMAC", "0") != "0"   # four v_fmac_f32 per step instead of two v_pk_fma_f32
+P64 = [[20, 22], [24, 26]]                        # B64: even-aligned pairs, lo becomes the LDS address, hi is the value
+
+# scalars
+S_C = 36                      # groups the current quad still has after this one
+S_REM = 38                    # chunks left in this tile, the one about to start included
+S_PTR = 40                    # s[40:41] entry stream pointer of the chunk about to start
+S_STP = 42                    # s[42:43] steps table of the current tile (this wave's 16 quads)
+S_T, S_NT, S_TABS, S_BUF, S_NCH, S_OFF8 = 44, 45, 47, 48, 49, 50
+S_A, S_B2, S_CC, S_D, S_E = 51, 52, 53, 54, 55
+S_INFO = 56                   # s[56:57] info pointer of the current 64-tile window
+S_4NCT, S_TLAST = 58, 59
+S_NP, S_DROW, S_DLDS = 61, 62, 63        # LDS-DMA pieces of the next tile still to issue; their next panel row / LDS address
+S_ND = 66                     # vector-memory operations issued since the last piece
+S_LINK, S_PRE, S_BASE = 68, 69, 70       # this tile preloads the next one; this tile was preloaded; entry buffer of its chunk 0
+S_LAST = 71
+S_PTRN = 72                   # s[72:73] entry stream pointer of the next tile
+S_DADDR = 78                  # s[78:79] scalar source address of the next LDS-DMA piece
+S_PSTEP, S_LIM, S_ROWBW = 80, 81, 82
+S_RET = 84                    # s[84:85] position 0 of the current slot's copy of the main loop
+S_CTL = 86                    # s[86:87] chunk routine of the next chunk's entry buffer
+S_CTLA = [88, 90, 92]         # s[88:93] the three chunk routines
+S_BODY0 = 94                  # s[94:95] position 0 of slot 0's copy
+S_QM = 96                     # s[96:97] lanes that hold one of this wave's quads
+
+_uid = [0]
+
+
+def uid(prefix):
+    _uid[0] += 1
+    return f"{prefix}{_uid[0]}"
+
+
+def grp_a_parts(k):
+    """two steps issued: (address instructions, value instructions, panel row reads)"""
+    p = k % DEPTH
+    ex, ey = ECUR
+    adds, movs, reads = [], [], []
+    if B64:
+        for t in range(2):
+            adds.append(f"v_mov_b64_dpp v[{P64[p][t]}:{P64[p][t] + 1}], v[{ex}:{ey}] row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+        for t in range(2):
+            movs.append(f"v_add_u32 v{P64[p][t]}, v{P64[p][t]}, v{VLB}")
+        for t in range(2):
+            reads.append(f"ds_read_b128 v[{W[p][t]}:{W[p][t] + 3}], v{P64[p][t]}")
+        return adds, movs, reads
+    for t in range(2):
+        adds.append(f"v_add_u32_dpp v{A[p][t]}, v{ex}, v{VLB} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+    for t in range(2):
+        reads.append(f"ds_read_b128 v[{W[p][t]}:{W[p][t] + 3}], v{A[p][t]}")
+    for t in range(2):
+        movs.append(f"v_mov_b32_dpp v{B[p] + t}, v{ey} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+    return adds, movs, reads
+
+
+def grp_a(k, L):
+    adds, movs, reads = grp_a_parts(k)
+    if B64 or ILV:
+        L += adds + movs + reads      # (B64: the add sits between the move and the read; ILV: the reads as far behind their addresses as they go)
+    else:
+        L += adds + reads + movs
+
+
+def grp_fma_parts(s, k):
+    """the FMAs of group k into slot s's accumulators: (first step, second step)"""
+    p = k % DEPTH
+    a = ACC + 4 * s
+    out = []
+    for t in range(2):
+        w = W[p][t]
+        L = []
+        if FMAC:
+            val = P64[p][t] + 1 if B64 else B[p] + t
+            for c in range(4):
+                L.append(f"v_fmac_f32 v{a + c}, v{val}, v{w + c}")
+        else:
+            if B64:
+                b, sel = P64[p][t], "op_sel:[0,1,0] op_sel_hi:[1,1,1]"    # the value is the pair's upper half
+            else:
+                b, sel = B[p], ("op_sel_hi:[1,0,1]" if t == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+            L.append(f"v_pk_fma_f32 v[{a}:{a + 1}], v[{w}:{w + 1}], v[{b}:{b + 1}], v[{a}:{a + 1}] {sel}")
+            L.append(f"v_pk_fma_f32 v[{a + 2}:{a + 3}], v[{w + 2}:{w + 3}], v[{b}:{b + 1}], v[{a + 2}:{a + 3}] {sel}")
+        out.append(L)
+    return out
+
+
+def wait_vmcnt(L, sreg, maxn):
+    """s_waitcnt vmcnt(min(s[sreg], maxn)): the count is a run-time value, the instruction takes an immediate"""
+    end = uid("wv_end")
+    labels = [uid("wv") for _ in range(maxn + 1)]
+    for n in range(maxn, 0, -1):
+        L += [f"s_cmp_ge_u32 s{sreg}, {n}", f"s_cbranch_scc1 {labels[n]}"]
+    L += ["s_waitcnt vmcnt(0)", f"s_branch {end}"]
+    for n in range(1, maxn + 1):
+        L += [f"{labels[n]}:", f"s_waitcnt vmcnt({n})"]
+        if n < maxn:
+            L.append(f"s_branch {end}")
+    L.append(f"{end}:")
+
+
+def dma_tile_setup(L):
+    """scalar source address of this wave's first piece of tile S_DROW: X + (S_DROW + 20 * wave * nct) * stride"""
+    L += [f"s_add_u32 s{S_A}, s{S_DROW}, s{S_ROWBW}",
+          f"s_mul_hi_u32 s{S_DADDR + 1}, s{S_A}, %[stride]", f"s_mul_i32 s{S_DADDR}, s{S_A}, %[stride]",
+          f"s_add_u32 s{S_DADDR}, s{S_DADDR}, %[xlo]", f"s_addc_u32 s{S_DADDR + 1}, s{S_DADDR + 1}, %[xhi]"]
+
+
+def dma_piece(L):
+    """one 1 KiB LDS-DMA piece of the next tile: 4 panel rows x 256 bytes (lane group g: row S_DROW + (20 wave + g) nct,
+    lane: 16 bytes of it).  The source address is scalar (s[S_DADDR] + the lane's constant offset) unless one of the four
+    rows lies past the panel's end: those pieces (the last one or two of a tile) clamp the row per lane."""
+    slow, done = uid("dmaslow"), uid("dmadone")
+    L += [f"s_cmp_gt_i32 s{S_DROW}, s{S_LIM}", f"s_cbranch_scc1 {slow}"]
+    L.append(f"s_mov_b32 m0, s{S_DLDS}")
+    L.append("s_nop 0")
+    L.append(f"global_load_lds_dwordx4 %[voff], s[{S_DADDR}:{S_DADDR + 1}]")
+    L.append(f"s_branch {done}")
+    L.append(f"{slow}:")
+    # 64-bit per-lane source address: panels above 4 GiB exist (10M rows x 128 columns)
+    L.append(f"v_add_u32 v{VT}, s{S_DROW}, %[rowb0]")
+    L.append(f"v_min_u32 v{VT}, %[prm1], v{VT}")
+    L.append(f"v_mul_hi_u32 v{VA64 + 1}, v{VT}, %[stride]")
+    L.append(f"v_mul_lo_u32 v{VA64}, v{VT}, %[stride]")
+    L.append(f"v_add_co_u32 v{VA64}, vcc, %[col16], v{VA64}")
+    L.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, 0, v{VA64 + 1}, vcc")
+    L.append(f"v_mov_b32 v{VT}, %[xhi]")                      # (an SGPR operand beside vcc would be a second constant-bus read)
+    L.append(f"v_add_co_u32 v{VA64}, vcc, %[xlo], v{VA64}")
+    L.append(f"v_addc_co_u32 v{VA64 + 1}, vcc, v{VT}, v{VA64 + 1}, vcc")
+    L.append(f"s_mov_b32 m0, s{S_DLDS}")
+    L.append("s_nop 0")
+    L.append(f"global_load_lds_dwordx4 v[{VA64}:{VA64 + 1}], off")
+    L.append(f"{done}:")
+    L.append(f"s_add_u32 s{S_DROW}, s{S_DROW}, s{S_4NCT}")
+    L.append(f"s_add_u32 s{S_DLDS}, s{S_DLDS}, 0x400")
+    L += [f"s_add_u32 s{S_DADDR}, s{S_DADDR}, s{S_PSTEP}", f"s_addc_u32 s{S_DADDR + 1}, s{S_DADDR + 1}, 0"]
+    L += [f"s_sub_u32 s{S_NP}, s{S_NP}, 1", f"s_mov_b32 s{S_ND}, 0"]
+
+
+def ptr_from_off8(L, s_off8, dst, base):
+    """s[dst:dst+1] = base (64-bit operand name) + 64 * s_off8   (s_off8: entry offset in units of 8 entries)"""
+    L.append(f"s_lshl_b32 s{S_CC}, s{s_off8}, 6")
+    L.append(f"s_lshr_b32 s{S_D}, s{s_off8}, 26")
+    L.append(f"s_mov_b64 s[{dst}:{dst + 1}], %[{base}]")
+    L.append(f"s_add_u32 s{dst}, s{dst}, s{S_CC}")
+    L.append(f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}")
+
+
+def set_ret(L, s):
+    """S_RET = position 0 of slot s's copy"""
+    if s == 0:
+        L.append(f"s_mov_b64 s[{S_RET}:{S_RET + 1}], s[{S_BODY0}:{S_BODY0 + 1}]")
+    else:
+        L += [f"s_add_u32 s{S_RET}, s{S_BODY0}, body_{s}_0-body_0_0", f"s_addc_u32 s{S_RET + 1}, s{S_BODY0 + 1}, 0"]
+
+
+def bodies(L):
+    """RG copies of a chunk's eight two-step groups.  Position k of slot s: the FMAs of group k into slot s's accumulators,
+    then group k + 2 issued; the quad's counter; fall through to position k + 1 (position 7: the chunk routine)."""
+    for s in range(RG):
+        for k in range(8):
+            L.append(f"body_{s}_{k}:")
+            ahead = min(DEPTH, 8 - k) - 1
+            L.append(f"s_waitcnt lgkmcnt({2 * ahead})")
+            f0, f1 = grp_fma_parts(s, k)
+            if k + DEPTH < 8 and ILV and not B64:
+                # the two steps' FMAs go to the same accumulators: the next group's address / value instructions between them
+                adds, movs, reads = grp_a_parts(k + DEPTH)
+                L += f0 + adds + f1 + movs + reads
+            else:
+                L += f0 + f1
+                if k + DEPTH < 8:
+                    grp_a(k + DEPTH, L)
+            L.append(f"s_sub_u32 s{S_C}, s{S_C}, 1")
+            L.append(f"s_cbranch_scc1 land_{s + 1}_{k}")          # the quad's last group: on to the next non-empty quad
+        L.append(f"s_setpc_b64 s[{S_CTL}:{S_CTL + 1}]")
+
+
+def stubs(L):
+    """land_s_k: slot s takes over behind position k (k = 7: at the next chunk's position 0, through the chunk routine).
+    Empty quads (no step in this tile) pass the turn on; behind the last slot the tile is done."""
+    for k in range(8):
+        for s in range(1, RG + 1):
+            L.append(f"land_{s}_{k}:")
+            if s == RG:
+                L.append("s_branch tile_done")
+                continue
+            L += [f"v_readlane_b32 s{S_C}, v{VCNT}, {s}", f"s_cmp_lt_i32 s{S_C}, 0", f"s_cbranch_scc1 land_{s + 1}_{k}"]
+            set_ret(L, s)
+            if k < 7:
+                L.append(f"s_branch body_{s}_{k + 1}")
+            else:
+                L.append(f"s_setpc_b64 s[{S_CTL}:{S_CTL + 1}]")
+    # tile entry: the first non-empty quad, then the first chunk's routine
+    L.append("enter_0:")
+    L += [f"v_readlane_b32 s{S_C}, v{VCNT}, 0", f"s_cmp_lt_i32 s{S_C}, 0", "s_cbranch_scc1 land_1_7"]
+    set_ret(L, 0)
+    L.append(f"s_setpc_b64 s[{S_CTL}:{S_CTL + 1}]")
+
+
+def chunk_routines(L, pattern):
+    """ctl_r: the chunk in entry buffer r is about to run.  Its entries are complete at vmcnt(2): every chunk slot issues
+    exactly one entry load, as its last vector-memory operation, so two younger loads (and whatever came with them) may
+    still be out."""
+    for r in range(3):
+        e = EB[r]
+        L.append(f"ctl_{r}:")
+        L.append("s_waitcnt vmcnt(2)")
+        L += [f"v_mov_b32 v{ECUR[0]}, v{e[0]}", f"v_mov_b32 v{ECUR[1]}, v{e[1]}"]
+        if pattern:
+            # pattern mode (MaskedSparsePCA's projection, quirk Q3): every stored non-zero value counts as 1, zeros
+            # (padding, and stored zeros, which the caller handles) as 0
+            L += ["s_nop 0", f"v_cmp_neq_f32 vcc, 0, v{ECUR[1]}", f"v_cndmask_b32 v{ECUR[1]}, 0, 1.0, vcc"]
+        # one LDS-DMA piece of the next tile while there are any (out of line)
+        L += [f"s_cmp_lg_u32 s{S_NP}, 0", f"s_cbranch_scc1 dma_{r}", f"dmaback_{r}:"]
+        # the buffer's next load: three chunks ahead in this tile; in the last three slots the next tile's first chunks (linked)
+        L += [f"s_cmp_le_u32 s{S_REM}, 3", f"s_cbranch_scc1 tail_{r}",
+              f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536 nt", f"issued_{r}:"]
+        L += [f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200", f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0",
+              f"s_sub_u32 s{S_REM}, s{S_REM}, 1",
+              f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[(r + 1) % 3]}:{S_CTLA[(r + 1) % 3] + 1}]"]
+        for k in range(DEPTH):
+            grp_a(k, L)
+        L.append(f"s_setpc_b64 s[{S_RET}:{S_RET + 1}]")
+    for r in range(3):
+        e = EB[r]
+        L.append(f"dma_{r}:")
+        dma_piece(L)
+        L.append(f"s_branch dmaback_{r}")
+        # last three slots of a tile: chunk 3 - rem of the next tile when linked (its step counts go first, rem == 3);
+        # otherwise a load nobody reads, so that the slot still issues one (the wait counts rely on it)
+        L += [f"tail_{r}:", f"s_cmp_eq_u32 s{S_LINK}, 0", f"s_cbranch_scc1 dummy_{r}",
+              f"s_cmp_lg_u32 s{S_REM}, 3", f"s_cbranch_scc1 nocnt_{r}",
+              f"global_load_ushort v{VCNT2}, %[l2c], s[{S_STP}:{S_STP + 1}] offset:512",
+              f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"nocnt_{r}:",
+              f"s_sub_u32 s{S_A}, 3, s{S_REM}", f"s_lshl_b32 s{S_A}, s{S_A}, 9", f"v_add_u32 v{VT}, s{S_A}, %[eoff]",
+              f"global_load_dwordx2 v[{e[0]}:{e[1]}], v{VT}, s[{S_PTRN}:{S_PTRN + 1}] nt", f"s_branch issued_{r}",
+              f"dummy_{r}:", f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] nt", f"s_branch issued_{r}"]
+
+
+def body(pattern):
+    L = []
+    # accumulators <- 0
+    for i in range(4 * RG):
+        L.append(f"v_mov_b32 v{ACC + i}, 0")
+    L += [f"s_mov_b32 s{S_T}, 0", f"s_mov_b32 s{S_NT}, %[ntiles]", f"s_mov_b32 s{S_TABS}, %[t0]",
+          f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], 2",
+          f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1",
+          f"s_mov_b32 s{S_ND}, 0", f"s_mov_b32 s{S_PRE}, 0", f"s_mov_b32 s{S_BASE}, 0", f"s_mov_b64 s[{S_STP}:{S_STP + 1}], %[stp]"]
+    # code addresses: the three chunk routines and slot 0's copy of the main loop
+    L += [f"s_getpc_b64 s[{S_BODY0}:{S_BODY0 + 1}]", "pcref:"]
+    for r in range(3):
+        L += [f"s_add_u32 s{S_CTLA[r]}, s{S_BODY0}, ctl_{r}-pcref", f"s_addc_u32 s{S_CTLA[r] + 1}, s{S_BODY0 + 1}, 0"]
+    L += [f"s_add_u32 s{S_BODY0}, s{S_BODY0}, body_0_0-pcref", f"s_addc_u32 s{S_BODY0 + 1}, s{S_BODY0 + 1}, 0"]
+    # lanes that hold a quad of this wave: lane < my_quads  (l2 = 2 * lane)
+    L += [f"s_lshl_b32 s{S_A}, %[myq], 1", f"v_cmp_gt_u32 vcc, s{S_A}, %[l2]", f"s_mov_b64 s[{S_QM}:{S_QM + 1}], vcc"]
+    L += [f"v_readfirstlane_b32 s{S_ROWBW}, %[rowb0]", f"s_mul_i32 s{S_PSTEP}, s{S_4NCT}, %[stride]",
+          f"s_mul_i32 s{S_LIM}, %[nct], 3", f"s_add_u32 s{S_LIM}, s{S_LIM}, s{S_ROWBW}", f"s_sub_u32 s{S_LIM}, %[prm1], s{S_LIM}"]
+    # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
+    L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
+    # first tile: this wave's five pieces into buffer 0, synchronously
+    L += [f"s_mov_b32 s{S_DROW}, s{S_TABS}", f"s_mov_b32 s{S_DLDS}, %[wdma]", f"s_mov_b32 s{S_NP}, 5"]
+    dma_tile_setup(L)
+    L += ["first_pieces:"]
+    dma_piece(L)
+    L += [f"s_cmp_lg_u32 s{S_NP}, 0", "s_cbranch_scc1 first_pieces", "s_waitcnt vmcnt(0)"]
+    L += ["tile_top:"]   # ---- tile loop
+    # a new 64-tile window of the info table (tiles are never linked across windows)
+    L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"s_cmp_lg_u32 s{S_A}, 0", "s_cbranch_scc1 same_window", f"s_cmp_eq_u32 s{S_T}, 0",
+          "s_cbranch_scc1 same_window", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
+          f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]", "s_waitcnt vmcnt(0)", "same_window:"]
+    L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}",
+          f"s_and_b32 s{S_NCH}, s{S_NCH}, 0xffff"]
+    ptr_from_off8(L, S_OFF8, S_PTR, "ent")
+    # link to the next tile?  (same info window, both with at least three chunks)
+    L += [f"s_mov_b32 s{S_LINK}, 0", f"s_add_u32 s{S_B2}, s{S_T}, 1", f"s_cmp_ge_u32 s{S_B2}, s{S_NT}", "s_cbranch_scc1 no_link",
+          f"s_and_b32 s{S_B2}, s{S_B2}, 63", f"s_cmp_eq_u32 s{S_B2}, 0", "s_cbranch_scc1 no_link", f"s_cmp_lt_u32 s{S_NCH}, 3", "s_cbranch_scc1 no_link",
+          f"v_readlane_b32 s{S_LAST}, v{VINFO[1]}, s{S_B2}", f"s_and_b32 s{S_LAST}, s{S_LAST}, 0xffff", f"s_cmp_lt_u32 s{S_LAST}, 3", "s_cbranch_scc1 no_link",
+          f"v_readlane_b32 s{S_LAST}, v{VINFO[0]}, s{S_B2}", f"s_mov_b32 s{S_LINK}, 1"]
+    ptr_from_off8(L, S_LAST, S_PTRN, "ent")
+    L += ["no_link:"]
+    # a tile that was not preloaded: its first three chunks and its step counts
+    L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 preloaded"]
+    for i, e in enumerate(EB):
+        L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i} nt")
+    L.append(f"global_load_ushort v{VCNT2}, %[l2c], s[{S_STP}:{S_STP + 1}]")
+    L += [f"s_add_u32 s{S_ND}, s{S_ND}, 4", f"s_mov_b32 s{S_BASE}, 0", "preloaded:"]
+    # this wave's pieces of the tile have landed: wait for all but what was issued after the last of them
+    wait_vmcnt(L, S_ND, 6)
+    L += ["s_barrier"]
+    # the step counts (issued before the last three entry loads of a linked predecessor); everything of a tile that loaded its own
+    L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 cnt_pre", "s_waitcnt vmcnt(0)", "s_branch cnt_ok", "cnt_pre:", "s_waitcnt vmcnt(3)", "cnt_ok:"]
+    L += [f"v_lshrrev_b32 v{VCNT}, 1, v{VCNT2}", f"v_add_u32 v{VCNT}, -1, v{VCNT}", f"s_mov_b64 vcc, s[{S_QM}:{S_QM + 1}]",
+          f"v_cndmask_b32 v{VCNT}, -1, v{VCNT}, vcc"]
+    # pieces of the next tile go to the other buffer (the last tile reloads itself: harmless)
+    L += [f"s_add_u32 s{S_DROW}, s{S_TABS}, 1", f"s_min_u32 s{S_DROW}, s{S_DROW}, s{S_TLAST}", f"s_sub_u32 s{S_DLDS}, {TILE_B}, s{S_BUF}",
+          f"s_add_u32 s{S_DLDS}, s{S_DLDS}, %[wdma]", f"s_mov_b32 s{S_NP}, 5"]
+    dma_tile_setup(L)
+    L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}"]
+    # the routine of chunk 0's entry buffer
+    L += [f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[0]}:{S_CTLA[0] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 0", "s_cbranch_scc1 ctl_set",
+          f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[1]}:{S_CTLA[1] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 ctl_set",
+          f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[2]}:{S_CTLA[2] + 1}]", "ctl_set:"]
+    L += [f"s_cmp_eq_u32 s{S_NCH}, 0", "s_cbranch_scc1 tile_done", "s_branch enter_0"]
+    bodies(L)
+    stubs(L)
+    chunk_routines(L, pattern)
+    L += ["tile_done:", "s_waitcnt lgkmcnt(0)"]
+    # pieces the chunks did not issue (fewer than five chunks)
+    L += [f"s_cmp_eq_u32 s{S_NP}, 0", "s_cbranch_scc1 pieces_done", "more_pieces:"]
+    dma_piece(L)
+    L += [f"s_cmp_lg_u32 s{S_NP}, 0", "s_cbranch_scc1 more_pieces", "pieces_done:"]
+    # the next tile starts in the buffer after this tile's last chunk when it was preloaded
+    L += [f"s_add_u32 s{S_BASE}, s{S_BASE}, s{S_NCH}", "base_mod:", f"s_cmp_lt_u32 s{S_BASE}, 3", "s_cbranch_scc1 base_ok", f"s_sub_u32 s{S_BASE}, s{S_BASE}, 3",
+          "s_branch base_mod", "base_ok:", f"s_mov_b32 s{S_PRE}, s{S_LINK}"]
+    L += [f"s_add_u32 s{S_T}, s{S_T}, 1", f"s_add_u32 s{S_TABS}, s{S_TABS}, 1",
+          f"s_add_u32 s{S_STP}, s{S_STP}, 0x200", f"s_addc_u32 s{S_STP + 1}, s{S_STP + 1}, 0",
+          f"s_sub_u32 s{S_BUF}, {TILE_B}, s{S_BUF}", f"s_cmp_lt_u32 s{S_T}, s{S_NT}", "s_cbranch_scc1 tile_top"]
+    L += ["s_waitcnt vmcnt(0)"]
+    return L
+
+
+def uniq_labels(L):
+    """inline asm may be emitted more than once per module: named labels get the %= suffix"""
+    names = set()
+    for ln in L:
+        m = re.match(r"^([a-z][a-z0-9_]*):$", ln)
+        if m:
+            names.add(m.group(1))
+    pat = re.compile(r"\b(" + "|".join(sorted(names, key=len, reverse=True)) + r")\b")
+    return [pat.sub(lambda m: m.group(1) + "_%=", ln) for ln in L]
+
+
+def set_depth_regs():
+    global A, B, W
+    if DEPTH == 3:
+        top = ACC + 4 * RG
+        A = [[20, 21], [22, 23], [50, 51]]
+        B = [24, 26, 52]
+        W = [[32, 36], [40, 44], [top, top + 4]]
+    assert not (DEPTH == 3 and B64)
+
+
+def clobbers():
+    v = [f"v{i}" for i in range(10, 50)]
+    if DEPTH == 3:
+        v += [f"v{i}" for i in range(50, 54)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 8)]
+    s = [f"s{i}" for i in range(36, 98)]
+    return v + s + ["memory", "scc", "m0", "vcc"]
+
+
+def main():
+    global RG
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "single-algebra_amd", "csrc", "spmm_dq2_gen.h")
+    with open(path, "w") as out:
+        out.write("// generated by tools/gen_spmm_dq2.py -- do not edit; the generator documents the structure\n")
+        out.write(f"#define DQ2_ACC_BASE {ACC}\n#define DQ2_TILE_BYTES {TILE_B}\n")
+        for rg in (8, 16):   # 512-row and 1024-row blocks
+            for pattern in (False, True):
+                RG = rg
+                set_depth_regs()
+                _uid[0] = 0
+                L = uniq_labels(body(pattern))
+                name = f"DQ2_MAIN_ASM_{rg}" + ("_PAT" if pattern else "")
+                out.write(f"#define {name} \\\n")
+                for ln in L:
+                    out.write(f'  "{ln}\\n" \\\n')
+                out.write("\n")
+                print(f"wrote {name}: {len(L)} lines")
+            out.write(f"#define DQ2_MAIN_CLOBBERS_{rg} " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+
+
+if __name__ == "__main__":
+    main()
