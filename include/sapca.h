@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define SAPCA_ABI_VERSION 2   /* 2: sapca_timings grew sweep_kernel / sweep_slots_*; sapca_comm_rccl_available */
+#define SAPCA_ABI_VERSION 3   /* 2: sapca_timings grew sweep_kernel / sweep_slots_*; sapca_comm_rccl_available
+                                 3: sapca_multi_* (one handle, several GPUs), sapca_upload_values_changed */
 
 typedef struct sapca_handle_s* sapca_handle;
 
@@ -306,6 +307,41 @@ typedef int (*sapca_allreduce_fn)(void* ctx, void* buf, uint64_t count, int32_t 
 sapca_status sapca_comm_set_callback(sapca_handle h, uint32_t nranks, uint32_t rank, sapca_allreduce_fn fn, void* ctx);
 /* Invokes the handle's collective once on a caller buffer (plumbing self-test).               */
 sapca_status sapca_comm_allreduce(sapca_handle h, void* buf, uint64_t count, int32_t dtype);
+
+
+/* ---- one handle, several GPUs, one calling thread (SURVEY.md §8b "Threading", §8e) ----------
+ * The reference call is ONE fit_transform(&CsrMatrix) from one thread (sparse/mod.rs:355-358;
+ * masked :616-619).  A sapca_multi owns one member handle per listed device; every call below
+ * splits the HOST CsrMatrix into nnz-balanced contiguous row ranges (sapca_partition_rows),
+ * runs the matching sapca_*_csr_* entry point on every shard from a host thread per device, and
+ * blocks until all are done.  The members are the ranks of one communicator: RCCL between
+ * distinct devices, an in-process all-reduce through page-locked host memory when a device is
+ * listed more than once (a one-GPU box rehearsing the path) or librccl does not resolve.
+ * `out` (m x n_components, row-major, HOST) receives every shard's rows in place.  The fitted
+ * state is replicated and bitwise identical on all members: read it from any member with the
+ * sapca_get_* functions (sapca_multi_member(mh, 0)); sapca_set_omega_* must be applied to every
+ * member.  A sapca_multi is not thread-safe for concurrent calls, like a handle.                */
+typedef struct sapca_multi_s* sapca_multi;
+sapca_status sapca_multi_create(const sapca_options* opts /* device_id and stream are ignored */,
+                                const int32_t* device_ids, uint32_t n_devices, sapca_multi* out);
+void sapca_multi_destroy(sapca_multi mh);
+const char* sapca_multi_last_error(sapca_multi mh /* NULL: the last failed sapca_multi_create of this thread */);
+uint32_t sapca_multi_n_devices(sapca_multi mh);
+sapca_handle sapca_multi_member(sapca_multi mh, uint32_t i);
+int sapca_multi_uses_rccl(sapca_multi mh);
+sapca_status sapca_multi_set_mask(sapca_multi mh, const uint8_t* mask, size_t n);
+sapca_status sapca_multi_fit_csr_f32(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                     const uint64_t* row_offsets, const uint64_t* col_indices, const float* values);
+sapca_status sapca_multi_fit_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                     const uint64_t* row_offsets, const uint64_t* col_indices, const double* values);
+sapca_status sapca_multi_transform_csr_f32(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                           const uint64_t* row_offsets, const uint64_t* col_indices, const float* values, float* out);
+sapca_status sapca_multi_transform_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                           const uint64_t* row_offsets, const uint64_t* col_indices, const double* values, double* out);
+sapca_status sapca_multi_fit_transform_csr_f32(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                               const uint64_t* row_offsets, const uint64_t* col_indices, const float* values, float* out);
+sapca_status sapca_multi_fit_transform_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                               const uint64_t* row_offsets, const uint64_t* col_indices, const double* values, double* out);
 
 #ifdef __cplusplus
 }

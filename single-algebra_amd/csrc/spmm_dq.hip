@@ -51,27 +51,35 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 
-// One wave per (row block, tile, wave of the sweep): the entry offset and chunk count of that wave's stream.
+// One wave per (row block, tile): lane w < 16 computes the entry offset and chunk count of sweep wave w's stream, and the rank
+// of its step count among the four waves that share its SIMD (waves w, w + 4, w + 8, w + 12: the longest gets 3) -- the
+// sweep's issue priority for that tile.
 __global__ void __launch_bounds__(256)
 dq_info_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __restrict__ chunk_off,
                const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, uint32_t* __restrict__ info, int64_t nchunks) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t wpb = blockDim.x / WAVE, ntasks = nchunks * DQ_WAVES;
-  for (int64_t task = (int64_t)blockIdx.x * wpb + threadIdx.x / WAVE; task < ntasks; task += (int64_t)gridDim.x * wpb) {
-    const int64_t cidx = task / DQ_WAVES;
-    const int wave = (int)(task % DQ_WAVES);
+  const int64_t wpb = blockDim.x / WAVE;
+  for (int64_t cidx = (int64_t)blockIdx.x * wpb + threadIdx.x / WAVE; cidx < nchunks; cidx += (int64_t)gridDim.x * wpb) {
     const int rb = (int)(cidx / nct), t = (int)(cidx % nct);
     const int nrows = blk_row0[rb + 1] - blk_row0[rb];
     const int nquads = (nrows + 3) / 4;
-    const int quad0 = dq_first(wave, nquads), my_quads = dq_first(wave + 1, nquads) - quad0;
-    int n = lane < my_quads ? (int)steps[cidx * DQ_BLOCK_QUADS + quad0 + lane] : 0;   // my_quads <= 16
+    const int wave = lane & (DQ_WAVES - 1);
+    const int quad0 = dq_first(wave, nquads), my_quads = dq_first(wave + 1, nquads) - quad0;   // <= 16
+    int n = 0;
+    if (lane < DQ_WAVES)
+      for (int j = 0; j < my_quads; ++j) n += (int)steps[cidx * DQ_BLOCK_QUADS + quad0 + j];
+    int rank = 0;
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) n += __shfl_xor(n, off);
-    if (lane == 0) {
+    for (int d = 4; d < 16; d += 4) {
+      const int other = (wave + d) & 15;
+      const int no = __shfl(n, other);
+      rank += (no < n || (no == n && other < wave)) ? 1 : 0;
+    }
+    if (lane < DQ_WAVES) {
       const int64_t s = chunk_off[cidx] + (int64_t)wave_off[cidx * DQ_WAVES + wave];
       uint32_t* w = info + (((int64_t)rb * DQ_WAVES + wave) * nct + t) * 2;
       w[0] = (uint32_t)(s / 8);
-      w[1] = (uint32_t)((n + 15) / 16);
+      w[1] = (uint32_t)((n + 15) / 16) | ((uint32_t)rank << 16);
     }
   }
 }
@@ -184,7 +192,7 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   const size_t info_words = ((size_t)nchunks * DQ_WAVES + 64) * 2;   // (+ a 64-tile window of slack: the sweep loads whole windows)
   uint32_t* d_info = buf.dq_info.as<uint32_t>(info_words);
   SAPCA_HIP(hipMemsetAsync(d_info + (size_t)nchunks * DQ_WAVES * 2, 0, 64 * 2 * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(dq_info_kernel, dim3((unsigned)std::min<int64_t>(nchunks * DQ_WAVES / 4 + 1, 8192)), dim3(256), 0, s, op.blk_row0, op.nct,
+  hipLaunchKernelGGL(dq_info_kernel, dim3((unsigned)std::min<int64_t>(nchunks / 4 + 1, 8192)), dim3(256), 0, s, op.blk_row0, op.nct,
                      op.chunk_off, op.wave_off, reinterpret_cast<const uint16_t*>(op.steps), d_info, nchunks);
   SAPCA_HIP(hipGetLastError());
   // (the chunk count of a wave's stream in one tile: at most 16 quads x 65535 steps / 16 = 65535, the 16 bits the sweep reads)

@@ -1,4 +1,4 @@
-//! Raw bindings to `include/sapca.h` (ABI version 2).  UNTESTED SOURCE: written against the header,
+//! Raw bindings to `include/sapca.h` (ABI version 3).  UNTESTED SOURCE: written against the header,
 //! never compiled in the build image (no rustc).  One `extern "C"` item per header declaration that
 //! the safe wrapper uses; the `_f64` twins mirror the `_f32` ones.
 #![allow(non_camel_case_types)]
@@ -9,6 +9,11 @@ pub struct sapca_handle_s {
     _private: [u8; 0],
 }
 pub type sapca_handle = *mut sapca_handle_s;
+#[repr(C)]
+pub struct sapca_multi_s {
+    _private: [u8; 0],
+}
+pub type sapca_multi = *mut sapca_multi_s;
 
 pub const SAPCA_OK: c_int = 0;
 pub const SAPCA_ERR_ARG: c_int = 1;
@@ -74,6 +79,28 @@ extern "C" {
     pub fn sapca_get_mask_index_maps(h: sapca_handle, cols_to_use: *mut u64, cols_cap: usize, orig_to_masked: *mut i64,
                                      map_cap: usize) -> c_int;
     pub fn sapca_comm_rccl_available() -> c_int;
+
+    // one handle, several GPUs, one calling thread (ABI 3): the host CsrMatrix is split into nnz-balanced row ranges, one
+    // member handle and one host thread per device; fitted state is read from any member (sapca_multi_member(mh, 0))
+    pub fn sapca_multi_create(opts: *const sapca_options, device_ids: *const i32, n_devices: u32, out: *mut sapca_multi) -> c_int;
+    pub fn sapca_multi_destroy(mh: sapca_multi);
+    pub fn sapca_multi_last_error(mh: sapca_multi) -> *const c_char;
+    pub fn sapca_multi_n_devices(mh: sapca_multi) -> u32;
+    pub fn sapca_multi_member(mh: sapca_multi, i: u32) -> sapca_handle;
+    pub fn sapca_multi_uses_rccl(mh: sapca_multi) -> c_int;
+    pub fn sapca_multi_set_mask(mh: sapca_multi, mask: *const u8, n: usize) -> c_int;
+    pub fn sapca_multi_fit_csr_f32(mh: sapca_multi, m: u64, n: u64, nnz: u64, row_offsets: *const u64, col_indices: *const u64,
+                                   values: *const f32) -> c_int;
+    pub fn sapca_multi_fit_csr_f64(mh: sapca_multi, m: u64, n: u64, nnz: u64, row_offsets: *const u64, col_indices: *const u64,
+                                   values: *const f64) -> c_int;
+    pub fn sapca_multi_transform_csr_f32(mh: sapca_multi, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                         col_indices: *const u64, values: *const f32, out: *mut f32) -> c_int;
+    pub fn sapca_multi_transform_csr_f64(mh: sapca_multi, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                         col_indices: *const u64, values: *const f64, out: *mut f64) -> c_int;
+    pub fn sapca_multi_fit_transform_csr_f32(mh: sapca_multi, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                             col_indices: *const u64, values: *const f32, out: *mut f32) -> c_int;
+    pub fn sapca_multi_fit_transform_csr_f64(mh: sapca_multi, m: u64, n: u64, nnz: u64, row_offsets: *const u64,
+                                             col_indices: *const u64, values: *const f64, out: *mut f64) -> c_int;
     pub fn sapca_get_components_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;
     pub fn sapca_get_components_f64(h: sapca_handle, out: *mut f64, cap: usize) -> c_int;
     pub fn sapca_get_explained_variance_f32(h: sapca_handle, out: *mut f32, cap: usize) -> c_int;

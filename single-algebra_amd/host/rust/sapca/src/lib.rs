@@ -9,7 +9,7 @@
 //! Here T is bounded by the sealed trait `SapcaFloat`, implemented for exactly those two: it carries the
 //! `_f32` / `_f64` entry points of include/sapca.h as associated functions.
 //!
-//! UNTESTED SOURCE: written against include/sapca.h (ABI version 2), never compiled (no rustc in the build image).
+//! UNTESTED SOURCE: written against include/sapca.h (ABI version 3), never compiled (no rustc in the build image).
 use anyhow::{anyhow, Result};
 use nalgebra_sparse::CsrMatrix;
 use ndarray::{Array1, Array2};
@@ -38,6 +38,12 @@ pub trait SapcaFloat: sealed::Sealed + Copy + Default + num_traits::Zero + 'stat
                         out: *mut Self) -> i32;
     unsafe fn fit_transform(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self,
                             out: *mut Self) -> i32;
+    // the same three calls on a sapca_multi (one handle, several GPUs: the host matrix is sharded by rows inside the library)
+    unsafe fn multi_fit(mh: ffi::sapca_multi, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self) -> i32;
+    unsafe fn multi_transform(mh: ffi::sapca_multi, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self,
+                              out: *mut Self) -> i32;
+    unsafe fn multi_fit_transform(mh: ffi::sapca_multi, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self,
+                                  out: *mut Self) -> i32;
     unsafe fn feature_importances(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
     unsafe fn explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
     unsafe fn cumulative_explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32;
@@ -47,7 +53,7 @@ pub trait SapcaFloat: sealed::Sealed + Copy + Default + num_traits::Zero + 'stat
 }
 
 macro_rules! impl_sapca_float {
-    ($t:ty, $fit:ident, $transform:ident, $fit_transform:ident, $fi:ident, $evr:ident, $cevr:ident, $comp:ident, $ev:ident, $mean:ident) => {
+    ($t:ty, $fit:ident, $transform:ident, $fit_transform:ident, $mfit:ident, $mtransform:ident, $mfit_transform:ident, $fi:ident, $evr:ident, $cevr:ident, $comp:ident, $ev:ident, $mean:ident) => {
         impl SapcaFloat for $t {
             fn to_f64(self) -> f64 { self as f64 }
             unsafe fn fit(h: ffi::sapca_handle, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self) -> i32 {
@@ -61,6 +67,17 @@ macro_rules! impl_sapca_float {
                                     v: *const Self, out: *mut Self) -> i32 {
                 ffi::$fit_transform(h, m, n, nnz, ro, ci, v, out)
             }
+            unsafe fn multi_fit(mh: ffi::sapca_multi, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64, v: *const Self) -> i32 {
+                ffi::$mfit(mh, m, n, nnz, ro, ci, v)
+            }
+            unsafe fn multi_transform(mh: ffi::sapca_multi, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64,
+                                      v: *const Self, out: *mut Self) -> i32 {
+                ffi::$mtransform(mh, m, n, nnz, ro, ci, v, out)
+            }
+            unsafe fn multi_fit_transform(mh: ffi::sapca_multi, m: u64, n: u64, nnz: u64, ro: *const u64, ci: *const u64,
+                                          v: *const Self, out: *mut Self) -> i32 {
+                ffi::$mfit_transform(mh, m, n, nnz, ro, ci, v, out)
+            }
             unsafe fn feature_importances(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$fi(h, out, cap) }
             unsafe fn explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 { ffi::$evr(h, out, cap) }
             unsafe fn cumulative_explained_variance_ratio(h: ffi::sapca_handle, out: *mut Self, cap: usize) -> i32 {
@@ -72,16 +89,30 @@ macro_rules! impl_sapca_float {
         }
     };
 }
-impl_sapca_float!(f32, sapca_fit_csr_f32, sapca_transform_csr_f32, sapca_fit_transform_csr_f32, sapca_get_feature_importances_f32,
+impl_sapca_float!(f32, sapca_fit_csr_f32, sapca_transform_csr_f32, sapca_fit_transform_csr_f32, sapca_multi_fit_csr_f32,
+                  sapca_multi_transform_csr_f32, sapca_multi_fit_transform_csr_f32, sapca_get_feature_importances_f32,
                   sapca_get_explained_variance_ratio_f32, sapca_get_cumulative_explained_variance_ratio_f32,
                   sapca_get_components_f32, sapca_get_explained_variance_f32, sapca_get_mean_f32);
-impl_sapca_float!(f64, sapca_fit_csr_f64, sapca_transform_csr_f64, sapca_fit_transform_csr_f64, sapca_get_feature_importances_f64,
+impl_sapca_float!(f64, sapca_fit_csr_f64, sapca_transform_csr_f64, sapca_fit_transform_csr_f64, sapca_multi_fit_csr_f64,
+                  sapca_multi_transform_csr_f64, sapca_multi_fit_transform_csr_f64, sapca_get_feature_importances_f64,
                   sapca_get_explained_variance_ratio_f64, sapca_get_cumulative_explained_variance_ratio_f64,
                   sapca_get_components_f64, sapca_get_explained_variance_f64, sapca_get_mean_f64);
 
-struct Handle(ffi::sapca_handle);
-impl Drop for Handle { fn drop(&mut self) { unsafe { ffi::sapca_destroy(self.0) } } }
+/// `.0`: the handle the getters read (with several devices: member 0 -- the fitted state is replicated on all members);
+/// `.1`: the sapca_multi that owns the members, null for a single device.
+struct Handle(ffi::sapca_handle, ffi::sapca_multi);
+impl Drop for Handle {
+    fn drop(&mut self) {
+        unsafe { if self.1.is_null() { ffi::sapca_destroy(self.0) } else { ffi::sapca_multi_destroy(self.1) } }
+    }
+}
 unsafe impl Send for Handle {}
+
+fn check_multi(mh: ffi::sapca_multi, status: i32) -> Result<()> {
+    if status == ffi::SAPCA_OK { return Ok(()); }
+    let msg = unsafe { CStr::from_ptr(ffi::sapca_multi_last_error(mh)) }.to_string_lossy().into_owned();
+    Err(anyhow!(msg))
+}
 
 fn check(h: ffi::sapca_handle, status: i32) -> Result<()> {
     if status == ffi::SAPCA_OK { return Ok(()); }
@@ -90,7 +121,7 @@ fn check(h: ffi::sapca_handle, status: i32) -> Result<()> {
 }
 
 fn create(n_components: usize, alpha: f64, tolerance: f64, seed: u32, center: bool, verbose: bool,
-          method: SVDMethod, mask: Option<&[bool]>) -> Result<Handle> {
+          method: SVDMethod, mask: Option<&[bool]>, devices: &[i32]) -> Result<Handle> {
     let mut o: ffi::sapca_options = unsafe { std::mem::zeroed() };
     unsafe { ffi::sapca_options_default(&mut o) };
     o.n_components = n_components as u64;
@@ -109,10 +140,26 @@ fn create(n_components: usize, alpha: f64, tolerance: f64, seed: u32, center: bo
             };
         }
     }
+    if devices.len() > 1 {
+        // one estimator, several GPUs: rows of the CsrMatrix are range-partitioned inside the library
+        let mut mh: ffi::sapca_multi = std::ptr::null_mut();
+        let st = unsafe { ffi::sapca_multi_create(&o, devices.as_ptr(), devices.len() as u32, &mut mh) };
+        if st != ffi::SAPCA_OK {
+            let msg = unsafe { CStr::from_ptr(ffi::sapca_multi_last_error(std::ptr::null_mut())) }.to_string_lossy().into_owned();
+            return Err(anyhow!("sapca_multi_create failed with status {st}: {msg}"));
+        }
+        let h = Handle(unsafe { ffi::sapca_multi_member(mh, 0) }, mh);
+        if let Some(m) = mask {
+            let bytes: Vec<u8> = m.iter().map(|&b| b as u8).collect();
+            check_multi(mh, unsafe { ffi::sapca_multi_set_mask(mh, bytes.as_ptr(), bytes.len()) })?;
+        }
+        return Ok(h);
+    }
+    if let Some(&d) = devices.first() { o.device_id = d; }
     let mut h: ffi::sapca_handle = std::ptr::null_mut();
     let st = unsafe { ffi::sapca_create(&o, &mut h) };
     if st != ffi::SAPCA_OK { return Err(anyhow!("sapca_create failed with status {st}")); }
-    let h = Handle(h);
+    let h = Handle(h, std::ptr::null_mut());
     if let Some(m) = mask {
         let bytes: Vec<u8> = m.iter().map(|&b| b as u8).collect();
         check(h.0, unsafe { ffi::sapca_set_mask(h.0, bytes.as_ptr(), bytes.len()) })?;
@@ -127,6 +174,13 @@ impl<T: SapcaFloat> SparsePCA<T> {
     /// sparse/mod.rs:102-242
     pub fn fit(&mut self, x: &CsrMatrix<T>) -> Result<&mut Self> {
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
+        if !self.h.1.is_null() {
+            check_multi(self.h.1, unsafe {
+                T::multi_fit(self.h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+                             ci.as_ptr() as *const u64, v.as_ptr())
+            })?;
+            return Ok(self);
+        }
         check(self.h.0, unsafe {
             T::fit(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                    ci.as_ptr() as *const u64, v.as_ptr())
@@ -137,6 +191,13 @@ impl<T: SapcaFloat> SparsePCA<T> {
     pub fn transform(&self, x: &CsrMatrix<T>) -> Result<Array2<T>> {
         let mut out = Array2::<T>::zeros((x.nrows(), self.n_components));
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
+        if !self.h.1.is_null() {
+            check_multi(self.h.1, unsafe {
+                T::multi_transform(self.h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+                                   ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
+            })?;
+            return Ok(out);
+        }
         check(self.h.0, unsafe {
             T::transform(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                          ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
@@ -147,6 +208,13 @@ impl<T: SapcaFloat> SparsePCA<T> {
     pub fn fit_transform(&mut self, x: &CsrMatrix<T>) -> Result<Array2<T>> {
         let mut out = Array2::<T>::zeros((x.nrows(), self.n_components));
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
+        if !self.h.1.is_null() {
+            check_multi(self.h.1, unsafe {
+                T::multi_fit_transform(self.h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+                                       ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
+            })?;
+            return Ok(out);
+        }
         check(self.h.0, unsafe {
             T::fit_transform(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                              ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
@@ -203,12 +271,12 @@ impl<T: SapcaFloat> SparsePCA<T> {
 /// SparsePCABuilder<T> (sparse/mod.rs:375-484; defaults :392-401)
 pub struct SparsePCABuilder<T: SapcaFloat> {
     n_components: usize, alpha: f64, tolerance: f64, random_seed: Option<u32>, center: bool, verbose: bool,
-    svdmethod: SVDMethod, _t: PhantomData<T>,
+    svdmethod: SVDMethod, devices: Vec<i32>, _t: PhantomData<T>,
 }
 impl<T: SapcaFloat> Default for SparsePCABuilder<T> {
     fn default() -> Self {
         Self { n_components: 50, alpha: 1.0, tolerance: 1e-6, random_seed: Some(42), center: true, verbose: false,
-               svdmethod: SVDMethod::default(), _t: PhantomData }
+               svdmethod: SVDMethod::default(), devices: Vec::new(), _t: PhantomData }
     }
 }
 impl<T: SapcaFloat> SparsePCABuilder<T> {
@@ -220,10 +288,14 @@ impl<T: SapcaFloat> SparsePCABuilder<T> {
     pub fn center(mut self, c: bool) -> Self { self.center = c; self }
     pub fn verbose(mut self, v: bool) -> Self { self.verbose = v; self }
     pub fn svd_method(mut self, m: SVDMethod) -> Self { self.svdmethod = m; self }
+    /// Extension (not in the reference): the HIP devices to run on.  Empty = the current device; one = that device; several =
+    /// the rows of every matrix passed to fit / transform / fit_transform are range-partitioned over them inside the
+    /// library (include/sapca.h, sapca_multi_*), the call itself unchanged.
+    pub fn devices(mut self, d: Vec<i32>) -> Self { self.devices = d; self }
     /// The reference's `build()` is infallible; creating the GPU handle is not, hence the Result.
     pub fn build(self) -> Result<SparsePCA<T>> {
         let h = create(self.n_components, self.alpha, self.tolerance, self.random_seed.unwrap_or(42),
-                       self.center, self.verbose, self.svdmethod, None)?;
+                       self.center, self.verbose, self.svdmethod, None, &self.devices)?;
         Ok(SparsePCA { h, n_components: self.n_components, _t: PhantomData })
     }
 }
@@ -271,10 +343,11 @@ impl<T: SapcaFloat> MaskedSparsePCABuilder<T> {
     pub fn verbose(mut self, v: bool) -> Self { self.base = self.base.verbose(v); self }
     pub fn svd_method(mut self, m: SVDMethod) -> Self { self.base = self.base.svd_method(m); self }
     pub fn mask(mut self, mask: Vec<bool>) -> Self { self.mask = mask; self }
+    pub fn devices(mut self, d: Vec<i32>) -> Self { self.base = self.base.devices(d); self }
     pub fn build(self) -> Result<MaskedSparsePCA<T>> {
         let b = self.base;
         let h = create(b.n_components, b.alpha, b.tolerance, b.random_seed.unwrap_or(42), b.center,
-                       b.verbose, b.svdmethod, Some(&self.mask))?;
+                       b.verbose, b.svdmethod, Some(&self.mask), &b.devices)?;
         Ok(MaskedSparsePCA { inner: SparsePCA { h, n_components: b.n_components, _t: PhantomData }, mask_len: self.mask.len() })
     }
 }

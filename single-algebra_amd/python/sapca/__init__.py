@@ -5,3 +5,4 @@ Python is the test/bench host here; the product is libsapca.so (C ABI in include
 from ._lib import LIB_PATH, SapcaError, load  # noqa: F401
 from .pca import (DeviceCsr, MaskedSparsePCA, MaskedSparsePCABuilder, PowerIterationNormalizer,  # noqa: F401
                   SparsePCA, SparsePCABuilder, SVDMethod)
+from .multi import MultiDevice  # noqa: F401

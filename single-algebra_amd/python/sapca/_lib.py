@@ -50,12 +50,15 @@ _TYPED = [
     "sapca_get_feature_importances", "sapca_colstats_csr", "sapca_spmm_csr", "sapca_spmmt_csr",
     "sapca_normalize_panel", "sapca_generate_omega",
     "sapca_upload_csr", "sapca_normalize_csr_device", "sapca_log1p_csr_device", "sapca_stats_csr_device",
+    "sapca_multi_fit_csr", "sapca_multi_transform_csr", "sapca_multi_fit_transform_csr",
 ]
 _PLAIN = [
     "sapca_options_default", "sapca_abi_version", "sapca_create", "sapca_destroy", "sapca_last_error",
     "sapca_set_mask", "sapca_get_dims", "sapca_get_total_variance", "sapca_get_mask_index_maps",
     "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_rccl_available", "sapca_comm_init_rank",
     "sapca_comm_set_callback", "sapca_comm_allreduce", "sapca_upload_values_changed",
+    "sapca_multi_create", "sapca_multi_destroy", "sapca_multi_last_error", "sapca_multi_n_devices", "sapca_multi_member",
+    "sapca_multi_uses_rccl", "sapca_multi_set_mask",
 ]
 EXPORTED_SYMBOLS = _PLAIN + [f"{n}_{s}" for n in _TYPED for s in ("f32", "f64")]
 
@@ -92,6 +95,16 @@ def load():
     lib.sapca_destroy.restype = None
     lib.sapca_options_default.argtypes = [C.POINTER(Options)]
     lib.sapca_options_default.restype = None
+    lib.sapca_multi_create.argtypes = [C.POINTER(Options), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.sapca_multi_destroy.argtypes = [C.c_void_p]
+    lib.sapca_multi_destroy.restype = None
+    lib.sapca_multi_last_error.argtypes = [C.c_void_p]
+    lib.sapca_multi_last_error.restype = C.c_char_p
+    lib.sapca_multi_member.argtypes = [C.c_void_p, C.c_uint32]
+    lib.sapca_multi_member.restype = C.c_void_p
+    lib.sapca_multi_n_devices.argtypes = [C.c_void_p]
+    lib.sapca_multi_n_devices.restype = C.c_uint32
+    lib.sapca_multi_uses_rccl.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 

@@ -118,6 +118,8 @@ class _Estimator:
                 o.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         except ImportError:
             pass
+        self._opts = o
+        self._borrowed = False     # (a member of a sapca_multi: the multi handle owns it)
         st = lib.sapca_create(C.byref(o), C.byref(self._h))
         if st != L.OK:
             raise L.SapcaError(st, (lib.sapca_last_error(None) or b"").decode())
@@ -127,7 +129,7 @@ class _Estimator:
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
+            if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):
                 L.load().sapca_destroy(self._h)
                 self._h = C.c_void_p()
         except Exception:

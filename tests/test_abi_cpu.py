@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/sapca.h but not exported"
     assert declared == set(L.EXPORTED_SYMBOLS)
-    assert lib.sapca_abi_version() == 2
+    assert lib.sapca_abi_version() == 3
 
 
 def test_options_struct_layout_matches_header():

@@ -1,0 +1,86 @@
+"""One handle, several GPUs, one calling thread (sapca_multi_*, SURVEY.md 8b "Threading" / 8e).
+
+A one-GPU box lists its device several times: the members then all-reduce through page-locked host memory inside the
+process, everything else (row partition, one host thread per member, the three all-reduce sites of a fit, the shards'
+rows of the projection written in place) is the product's multi-GPU path.  Reference: the same estimator on one handle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import sapca
+import sapca_oracle as O
+from sapca import _lib as L
+from sapca import synth
+from sapca import PowerIterationNormalizer as PIN
+from sapca import SVDMethod
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(m, n, dens, k, seed, dtype, centred=True):
+    p, i, v = synth.gapped_csr(m, n, dens, k, seed=seed, centred=centred, dtype=dtype)
+    return sp.csr_matrix((v.numpy(), i.numpy().astype(np.int64), p.numpy().astype(np.int64)), shape=(m, n))
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_randomized_fit_transform_sharded_inside_the_library(ndev):
+    m, n, k, p, q = 9000, 1200, 10, 6, 3
+    A = _host(m, n, 0.05, k, 3, torch.float32)
+    om = synth.gaussian_panel(n, k + p, 5).numpy()
+    make = lambda: (sapca.SparsePCABuilder.new().n_components(k).svd_method(SVDMethod.Random(p, q, PIN.QR)).build())
+    one = make().set_omega(om)
+    t1 = one.fit_transform(A)
+    md = sapca.MultiDevice(make(), [0] * ndev).set_omega(om)
+    assert not md.uses_rccl()                      # a device listed twice: the in-process transport
+    t = md.fit_transform(A)
+    np.testing.assert_allclose(md.singular_values_(np.float64), one.singular_values_(np.float64), rtol=2e-5)
+    assert O.subspace_angle(md.components_(np.float64), one.components_(np.float64)) < 2e-5
+    np.testing.assert_allclose(md.mean_(np.float64), one.mean_(np.float64), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(t, t1, atol=2e-4 * np.abs(t1).max())
+    # replicated state: every member answers alike, bit for bit
+    for i in range(1, ndev):
+        assert np.array_equal(md.member(i).components_(np.float32), md.member(0).components_(np.float32))
+    # a separate transform through the same handle (Q2: the per-column counts cross the shards)
+    t2 = md.transform(A)
+    np.testing.assert_allclose(t2, t, atol=1e-5 * np.abs(t).max())
+    # against the oracle too
+    ptr, idx, val = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
+    want = O.fit(ptr, idx, val, m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    assert O.subspace_angle(md.components_(np.float64), want.components) < 1e-4
+
+
+def test_masked_lanczos_f64_sharded_inside_the_library():
+    m, n, k = 6000, 900, 6
+    A = _host(m, n, 0.06, k, 9, torch.float64, centred=False)
+    mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
+    make = lambda: sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).svd_method(SVDMethod.Lanczos()).build()
+    one = make()
+    t1 = one.fit_transform(A)
+    md = sapca.MultiDevice(make(), [0, 0])
+    t = md.fit_transform(A)
+    np.testing.assert_allclose(md.singular_values_(np.float64), one.singular_values_(np.float64), rtol=1e-8)
+    assert O.subspace_angle(md.components_(np.float64), one.components_(np.float64)) < 1e-6
+    c1, o1 = one.mask_index_maps()
+    c2, o2 = md.mask_index_maps()
+    assert np.array_equal(c1, c2) and np.array_equal(o1, o2)          # bit-exact index maps on every member
+    np.testing.assert_allclose(t, t1, atol=1e-7 * np.abs(t1).max())
+
+
+def test_a_failing_shard_fails_the_call_and_releases_its_peers():
+    """shard 1 holds a column index past n: its upload refuses it; shard 0, already inside the first all-reduce, is released
+    (no hang) and the call reports the shard that failed in its own right"""
+    m, n, k = 4000, 500, 5
+    A = _host(m, n, 0.05, k, 1, torch.float32)
+    A.indices = A.indices.astype(np.int64)
+    A.indices[-1] = n + 3
+    md = sapca.MultiDevice(sapca.SparsePCABuilder.new().n_components(k).svd_method(SVDMethod.Random(4, 1, PIN.QR)).build(), [0, 0])
+    with pytest.raises(L.SapcaError, match="shard 1") as e:
+        md.fit(A)
+    assert e.value.status == L.ERR_ARG
+    # the handle is still usable
+    B = _host(m, n, 0.05, k, 1, torch.float32)
+    assert md.fit_transform(B).shape == (m, k)
+    with pytest.raises(L.SapcaError, match="mask vector length"):
+        sapca.MultiDevice(sapca.MaskedSparsePCABuilder.new().n_components(2).mask(np.ones(n + 1, bool))
+                          .svd_method(SVDMethod.Random(3, 1)).build(), [0, 0]).fit(B)

@@ -46,6 +46,7 @@ VA64 = 30         # v[30:31]: 64-bit source address of an LDS-DMA piece
 W = [[32, 36], [40, 44]]
 VCNT, VCNT2 = 48, 49   # two-step groups - 1 of this wave's quads in the current tile (lane j = quad j; -1: none); raw step counts of the next
 DEPTH = int(os.environ.get("DQ2_DEPTH", "2"))   # two-step groups in flight per wave (3: a third register set behind the accumulators)
+PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from the info table
 ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved with the next group's DPP instructions, reads last
 # experiment switches (environment, read when the header is generated)
 B64 = os.environ.get("DQ2_B64", "0") != "0"     # one 64-bit row_newbcast move per step ({offset, value}) + a plain add, instead of add_dpp + mov_dpp
@@ -319,8 +320,14 @@ def body(pattern):
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"s_cmp_lg_u32 s{S_A}, 0", "s_cbranch_scc1 same_window", f"s_cmp_eq_u32 s{S_T}, 0",
           "s_cbranch_scc1 same_window", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
           f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]", "s_waitcnt vmcnt(0)", "same_window:"]
-    L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}",
-          f"s_and_b32 s{S_NCH}, s{S_NCH}, 0xffff"]
+    L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"v_readlane_b32 s{S_OFF8}, v{VINFO[0]}, s{S_A}", f"v_readlane_b32 s{S_NCH}, v{VINFO[1]}, s{S_A}"]
+    if PRIO:
+        # issue priority for this tile: the rank of this wave's step count among the four waves of its SIMD (bits 16..17 of the
+        # info word): the waves of a SIMD then reach the tile's barrier together instead of leaving the longest to finish alone
+        L += [f"s_bfe_u32 s{S_B2}, s{S_NCH}, 0x20010", f"s_cmp_eq_u32 s{S_B2}, 0", "s_cbranch_scc1 prio0", f"s_cmp_eq_u32 s{S_B2}, 1", "s_cbranch_scc1 prio1",
+              f"s_cmp_eq_u32 s{S_B2}, 2", "s_cbranch_scc1 prio2", "s_setprio 3", "s_branch prio_set", "prio2:", "s_setprio 2", "s_branch prio_set",
+              "prio1:", "s_setprio 1", "s_branch prio_set", "prio0:", "s_setprio 0", "prio_set:"]
+    L += [f"s_and_b32 s{S_NCH}, s{S_NCH}, 0xffff"]
     ptr_from_off8(L, S_OFF8, S_PTR, "ent")
     # link to the next tile?  (same info window, both with at least three chunks)
     L += [f"s_mov_b32 s{S_LINK}, 0", f"s_add_u32 s{S_B2}, s{S_T}, 1", f"s_cmp_ge_u32 s{S_B2}, s{S_NT}", "s_cbranch_scc1 no_link",
