@@ -111,7 +111,8 @@ typedef struct sapca_timings {
   uint64_t lanczos_steps;
   uint32_t sweep_kernel;     /* randomized fits: 0 row-gather kernel, 1 staged-entry quad sweep,
                               * 2 DPP-fed quad sweep (spmm_dq.hip)                              */
-  uint32_t reserved0;
+  uint32_t at_sweep_pieces;  /* multi-rank randomized fits: 2 when the A^T sweeps ran in two pieces with the first
+                              * piece's panel all-reduce behind the second piece's sweep; else 1 (0: no sweep) */
   uint64_t sweep_slots_a;    /* entry slots (stored entries + padding) one A*X sweep walks; 0 on
                               * the row-gather kernel.  x 256 B (f32, 64 columns) = LDS gather bytes */
   uint64_t sweep_slots_at;   /* the same for one A^T*Y sweep                                    */

@@ -618,6 +618,12 @@ void sapca_destroy(sapca_handle h) {
     (void)hipStreamSynchronize(h->stream2);
     (void)hipStreamDestroy(h->stream2);
   }
+  if (h->stream_comm) {
+    (void)hipStreamSynchronize(h->stream_comm);
+    (void)hipStreamDestroy(h->stream_comm);
+    if (h->ev_piece) (void)hipEventDestroy(h->ev_piece);
+    if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
+  }
   if (h->stream3) {
     (void)hipStreamSynchronize(h->stream3);
     (void)hipStreamDestroy(h->stream3);

@@ -638,13 +638,76 @@ void Engine<T>::fit_randomized(H& h) {
     Scope sc(h, C_SPMM);
     k::spmm(A, &h.tiled_a, X, ld, Y, ld, ld, center ? cvec : nullptr, variant, h.split_scratch, s);
   };
+  // Multi-rank fits: the n x l panel of an A^T sweep is the one bandwidth-relevant collective.  Where the
+  // operator allows it the sweep runs in two pieces of its output rows, each cut finely enough to keep (nearly) every CU
+  // busy, and the first piece is all-reduced on a side stream while the second is swept; the second piece's collective
+  // carries the column sums.  A few CUs are left free for the collective's own kernels (a sweep workgroup takes all of a
+  // CU's LDS, nothing else fits beside it).  SAPCA_AT_OVERLAP=0 switches it off.
+  std::vector<int64_t> piece_rows;
+  bool overlap = false;
+  int64_t cut = 0;   // rows [0, cut) of the panel are all-reduced behind the first piece, the rest behind the second
+  int piece_wgs = 240;
+  h.at_sweep_pieces = 1u;
+  if constexpr (sizeof(T) == 4) {
+    const char* ov = getenv("SAPCA_AT_OVERLAP");   // (read per fit: the tests switch it)
+    const bool overlap_off = ov != nullptr && atoi(ov) == 0;
+    if (h.comm.active() && !overlap_off && variant != 1) {
+      // The pieces are whole row blocks of this rank's operator, and ranks cut their blocks differently (the block count
+      // follows the shard's own tile count): the ranks agree on one row count -- the smallest first piece, 0 if any rank
+      // cannot sweep in pieces -- so that every rank's collectives have the same sizes.  One small all-reduce per fit.
+      const bool mine = tiled && k::spmm_tiled_pieces_ok(h.tiled_at, 2, ld);
+      if (mine) k::spmm_tiled_piece_bounds(h.tiled_at, 2, piece_rows, s);
+      const uint32_t nr = h.comm.nranks;
+      std::vector<double> votes((size_t)nr, 0.0);
+      votes[h.comm.rank] = mine ? (double)piece_rows[1] : 0.0;
+      double* d_votes = h.votes.as<double>(nr);
+      SAPCA_HIP(hipMemcpyAsync(d_votes, votes.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+      h.comm.allreduce(d_votes, nr, 1, s);
+      SAPCA_HIP(hipMemcpyAsync(votes.data(), d_votes, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+      SAPCA_HIP(hipStreamSynchronize(s));
+      cut = (int64_t)*std::min_element(votes.begin(), votes.end());
+      overlap = mine && cut > 0 && cut < n_used;
+    }
+    h.at_sweep_pieces = overlap ? 2u : 1u;
+    if (overlap) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, h.device) == hipSuccess) piece_wgs = std::max(16, pr.multiProcessorCount - 16);
+      if (!h.stream_comm) {
+        SAPCA_HIP(hipStreamCreateWithFlags(&h.stream_comm, hipStreamNonBlocking));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_piece, hipEventDisableTiming));
+        SAPCA_HIP(hipEventCreateWithFlags(&h.ev_comm, hipEventDisableTiming));
+      }
+    }
+  }
   auto sweep_At = [&]() {  // X = Ac^T Y   (R9); partial products are summed over ranks
+    T* sv = h.comm.active() ? X + (size_t)n_used * ld : svec;   // one collective carries the l column sums of this rank's Y too
+    if constexpr (sizeof(T) == 4) {
+      if (overlap) {
+        const int wgs = piece_wgs;
+        const int64_t r1 = piece_rows[1];
+        {
+          Scope sc(h, C_SPMMT);
+          k::spmm_tiled_piece(h.tiled_at, 0, 2, wgs, 0, r1, Y, ld, X, ld, ld, h.split_scratch, s);
+          SAPCA_HIP(hipEventRecord(h.ev_piece, s));
+          k::spmm_tiled_piece(h.tiled_at, 1, 2, wgs, r1, n_used - r1, Y, ld, X, ld, ld, h.split_scratch2, s);
+        }
+        if (center) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
+        {
+          Scope cs(h, C_COMM);   // (device time from the first piece's collective being possible to the last one's end)
+          SAPCA_HIP(hipStreamWaitEvent(h.stream_comm, h.ev_piece, 0));
+          h.comm.allreduce(X, (uint64_t)cut * ld, kDtype, h.stream_comm);   // (cut <= r1: rows this rank has finished)
+          SAPCA_HIP(hipEventRecord(h.ev_comm, h.stream_comm));
+          h.comm.allreduce(X + (size_t)cut * ld, (uint64_t)(n_used - cut) * ld + (center ? (uint64_t)ld : 0), kDtype, s);
+          SAPCA_HIP(hipStreamWaitEvent(s, h.ev_comm, 0));
+        }
+        if (center) k::rank1_subtract(X, n_used, ld, mu, sv, s);
+        return;
+      }
+    }
     {
       Scope sc(h, C_SPMMT);
       k::spmm(At, &h.tiled_at, Y, ld, X, ld, ld, (const T*)nullptr, variant, h.split_scratch, s);
     }
-    // one collective per sweep: the l column sums of this rank's Y sit in the row after the panel
-    T* sv = h.comm.active() ? X + (size_t)n_used * ld : svec;
     if (center) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
     if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(X, (uint64_t)n_used * ld + (center ? (uint64_t)ld : 0), kDtype, s); }
     if (center) k::rank1_subtract(X, n_used, ld, mu, sv, s);
@@ -826,6 +889,7 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
                                 (double)n_used * l * sizeof(T) + (double)h.a_used.rows * l * sizeof(T);
     const bool tiled = h.opt.method == SAPCA_RANDOM && h.tiled_a.valid && h.tiled_at.valid;
     h.timings.sweep_kernel = !tiled ? 0u : (k::dq_usable(h.tiled_a, 64) && k::dq_usable(h.tiled_at, 64) && h.opt.spmm_variant != 1 ? 2u : 1u);
+    h.timings.at_sweep_pieces = h.opt.method == SAPCA_RANDOM ? h.at_sweep_pieces : 0u;
     h.timings.sweep_slots_a = tiled ? (uint64_t)h.tiled_a.total_entries : 0;
     h.timings.sweep_slots_at = tiled ? (uint64_t)h.tiled_at.total_entries : 0;
   }

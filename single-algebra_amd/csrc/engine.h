@@ -19,6 +19,8 @@ struct sapca_handle_s {
   // fit(): single-rank fits let that chain run beside the format builds AND the sweeps, and it copies the statistics to
   // the host itself (ev_kept: the kept columns' sums are in place on the main stream; ev_stats: the host copy has landed)
   hipStream_t stream3 = nullptr;
+  hipStream_t stream_comm = nullptr;   // the first piece's all-reduce of an A^T sweep swept in two pieces (multi-rank fits)
+  hipEvent_t ev_piece = nullptr, ev_comm = nullptr;
   hipEvent_t ev_kept = nullptr, ev_stats = nullptr;
   bool stats_on_side = false;
 
@@ -57,6 +59,7 @@ struct sapca_handle_s {
   uint64_t m_global = 0;
   std::vector<double> prep_mean;  // column means of the prepared matrix (n)
   double prep_total_var = 0;
+  uint32_t at_sweep_pieces = 1;   // 2: the last randomized fit swept A^T in two pieces (multi-rank overlap)
   bool q3_cancels = false;        // a kept column is well filled and of small spread: the masked projection subtracts entry by entry
   // the column sums on the host (sum | sumsq | row count), copied asynchronously: single-rank fits read them at the end
   // of fit() instead of stalling the stream between the preparation and the first sweep
@@ -94,7 +97,7 @@ struct sapca_handle_s {
   sapca::DevBuf idx16_a, idx16_b;                                 // 2-byte index copies of the two operators of a Lanczos step
   sapca::TiledBuffers tb_a, tb_at;                               // tile-major formats for the LDS-staged sweep
   sapca::TiledOp tiled_a, tiled_at;
-  sapca::DevBuf split_scratch;
+  sapca::DevBuf split_scratch, split_scratch2, votes;
 
   sapca::EventTimer timer;
   std::vector<std::pair<int, int>> spans;  // (category, event index) of the last fit/transform

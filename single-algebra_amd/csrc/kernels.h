@@ -1,6 +1,7 @@
 // Launchers of the hand-written gfx950 kernels.  Everything takes device pointers and a
 // stream; nothing here allocates except through the DevBuf scratch arguments.
 #pragma once
+#include <vector>
 #include "common.h"
 
 namespace sapca {
@@ -116,6 +117,11 @@ int tiled_tile_count(int64_t cols, int ldp);
 int tiled_geometry(int l);
 void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s);
+// the DPP-fed sweep in pieces of its output rows (spmm_tiled.hip): can the operator be swept so, the pieces' row bounds, one piece
+bool spmm_tiled_pieces_ok(const TiledOp& op, int npieces, int ldx);
+void spmm_tiled_piece_bounds(const TiledOp& op, int npieces, std::vector<int64_t>& bounds, hipStream_t s);
+void spmm_tiled_piece(const TiledOp& op, int piece, int npieces, int wgs, int64_t first_row, int64_t row_count, const float* X, int ldx, float* Y,
+                      int ldy, int ncols, DevBuf& scratch, hipStream_t s);
 void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
                 hipStream_t s);
 

@@ -12,6 +12,10 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s);
 bool dq_usable(const TiledOp& op, int ldx);
 // flags: 8 = pattern mode (every stored non-zero value reads as 1)
 void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s, int flags = 0);
+// the same over row blocks [rb0, rb1) with a split of the tile range chosen by the caller (`out` then holds nsplit slabs of
+// op.rows x ldo when nsplit > 1, slab sp at out + sp * op.rows * ldo: rows keep their absolute positions)
+void launch_dq_blocks(const TiledOp& op, int rb0, int rb1, int nsplit, int tiles_per_split, const float* X, int ldx, float* out, int ldo,
+                      int ncols, const float* cvec, hipStream_t s, int flags = 0);
 // out (m x k, leading dimension k) = sum over the stored entries of row i of (a_ij - mu_j) W[j][:k]   (quirk Q3) as two sweeps of
 // the operator's format plus a pass over the values for stored zeros.  W2 (cols x ldw) and tmp (m x k) are scratch.  Returns false
 // when the operator cannot take the DPP-fed sweep (nothing is launched).

@@ -89,9 +89,9 @@ __global__ void __launch_bounds__(DQ_THREADS)
 spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct,
                 const uint64_t* __restrict__ ent, const uint16_t* __restrict__ steps, const uint32_t* __restrict__ info,
                 int64_t panel_rows, const float* __restrict__ X, int ldx, int nsplit, int tiles_per_split,
-                float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec) {
+                float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec, int rb0) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int rb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
   const int g = lane / 16, q = lane % 16;
@@ -205,22 +205,31 @@ bool dq_usable(const TiledOp& op, int ldx) { return op.dq && (ldx == 64 || ldx =
 
 template <int RG>
 static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int flags,
-                        hipStream_t s) {
+                        hipStream_t s, int rb0, int rb1, int nsplit, int tiles_per_split) {
   static LdsAttrState attr[2];
   const bool pat = (flags & 8) != 0;
   const auto launch = [&](auto kern, LdsAttrState& a) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), DQ_LDS, a);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(op.nrb * op.nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm, op.nct,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rb1 - rb0) * nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm, op.nct,
                        reinterpret_cast<const uint64_t*>(op.ent), reinterpret_cast<const uint16_t*>(op.steps), op.dq_info, op.cols, X, ldx,
-                       op.nsplit, op.tiles_per_split, out, op.rows, ldo, ncols, cvec);
+                       nsplit, tiles_per_split, out, op.rows, ldo, ncols, cvec, rb0);
   };
   if (pat) launch(&spmm_dq_kernel<RG, true>, attr[1]);
   else launch(&spmm_dq_kernel<RG, false>, attr[0]);
 }
 
 void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s, int flags) {
-  if (op.block_rows == 1024) launch_dq_t<16>(op, X, ldx, out, ldo, ncols, cvec, flags, s);
-  else launch_dq_t<8>(op, X, ldx, out, ldo, ncols, cvec, flags, s);
+  launch_dq_blocks(op, 0, op.nrb, op.nsplit, op.tiles_per_split, X, ldx, out, ldo, ncols, cvec, s, flags);
+}
+
+// row blocks [rb0, rb1) only, their tile range cut into `nsplit` pieces of `tiles_per_split` tiles: the split is a matter of the
+// launch (the per-(block, wave, tile) tables do not depend on it), so a caller that sweeps the operator in halves -- the
+// row-sharded A^T sweep, whose first half is all-reduced while the second runs -- can keep every CU busy in each half
+void launch_dq_blocks(const TiledOp& op, int rb0, int rb1, int nsplit, int tiles_per_split, const float* X, int ldx, float* out, int ldo,
+                      int ncols, const float* cvec, hipStream_t s, int flags) {
+  if (rb1 <= rb0) return;
+  if (op.block_rows == 1024) launch_dq_t<16>(op, X, ldx, out, ldo, ncols, cvec, flags, s, rb0, rb1, nsplit, tiles_per_split);
+  else launch_dq_t<8>(op, X, ldx, out, ldo, ncols, cvec, flags, s, rb0, rb1, nsplit, tiles_per_split);
 }
 
 // ---- MaskedSparsePCA::transform (quirk Q3, /root/reference/src/dimred/pca/sparse_masked/mod.rs:488-529) through the sweep ---------

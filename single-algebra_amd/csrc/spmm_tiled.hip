@@ -356,6 +356,21 @@ __global__ void split_reduce_kernel(const VT* __restrict__ part, int nsplit, int
   }
 }
 
+// the same for a run of rows: slab sp starts `slab_stride` elements behind slab sp - 1
+__global__ void split_reduce_rows_kernel(const float* __restrict__ part, int nsplit, int64_t slab_stride, int64_t rows, int ldo, int ncols,
+                                         float* __restrict__ out, int ldy) {
+  const int64_t total = rows * ldo;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int j = (int)(i % ldo);
+    if (j >= ncols) continue;
+    float s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * slab_stride + i];
+    out[(i / ldo) * ldy + j] = s;
+  }
+}
+
 #undef SAPCA_PREFETCH
 #undef SAPCA_BOOKKEEPING
 
@@ -2201,6 +2216,46 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
       hipLaunchKernelGGL(split_reduce_kernel<float>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
                          op.ldp, ncp, cv, Y + c0, ldy);
     }
+  }
+  SAPCA_HIP(hipGetLastError());
+}
+
+// Output rows [first, first + count) of the DPP-fed sweep, for callers that sweep an operator in pieces (the row-sharded
+// A^T sweep of a multi-rank fit: a piece's all-reduce runs while the next piece is swept).  `piece` of `npieces`: the row
+// blocks are cut into npieces runs; every piece cuts its tile range finely enough to occupy `wgs` workgroups, its partial
+// slabs are summed in fixed order.  Requires natural row order (no row_perm: a block's rows are then a contiguous range of
+// the output) and a 64-column panel.  Returns false when the operator cannot be swept this way (nothing is launched).
+bool spmm_tiled_pieces_ok(const TiledOp& op, int npieces, int ldx) {
+  return op.valid && op.elem == 4 && op.fmt == 1 && dq_usable(op, ldx) && ldx == op.ldp && op.row_perm == nullptr && npieces >= 1 && op.nrb >= npieces;
+}
+
+// bounds[p] = first output row of piece p (bounds[npieces] = rows): one small copy from the device, synchronous
+void spmm_tiled_piece_bounds(const TiledOp& op, int npieces, std::vector<int64_t>& bounds, hipStream_t s) {
+  std::vector<int32_t> b((size_t)npieces + 1);
+  for (int p = 0; p <= npieces; ++p)
+    SAPCA_HIP(hipMemcpyAsync(&b[(size_t)p], op.blk_row0 + (int64_t)op.nrb * p / npieces, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SAPCA_HIP(hipStreamSynchronize(s));
+  bounds.assign(b.begin(), b.end());
+}
+
+void spmm_tiled_piece(const TiledOp& op, int piece, int npieces, int wgs, int64_t first_row, int64_t row_count, const float* X, int ldx, float* Y,
+                      int ldy, int ncols, DevBuf& scratch, hipStream_t s) {
+  SAPCA_CHECK(spmm_tiled_pieces_ok(op, npieces, ldx), SAPCA_ERR_ARG, "tiled sweep: operator cannot be swept in pieces");
+  const int rb0 = (int)((int64_t)op.nrb * piece / npieces), rb1 = (int)((int64_t)op.nrb * (piece + 1) / npieces);
+  int nsplit = std::max(1, std::min(op.nct, wgs / std::max(1, rb1 - rb0)));
+  const int tps = (op.nct + nsplit - 1) / nsplit;
+  nsplit = (op.nct + tps - 1) / tps;
+  const int64_t* first = &first_row;
+  const int64_t* count = &row_count;
+  float* part = nsplit > 1 ? scratch.as<float>((size_t)nsplit * op.rows * op.ldp) : nullptr;
+  if (nsplit > 1) {
+    launch_dq_blocks(op, rb0, rb1, nsplit, tps, X, ldx, part, op.ldp, op.ldp, nullptr, s);
+    const int64_t total = *count * (int64_t)op.ldp;
+    // (slabs keep absolute row positions: the piece's rows start at first * ldp in every slab, slabs are op.rows * ldp apart)
+    hipLaunchKernelGGL(split_reduce_rows_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part + *first * op.ldp, nsplit,
+                       op.rows * (int64_t)op.ldp, *count, op.ldp, ncols, Y + *first * ldy, ldy);
+  } else {
+    launch_dq_blocks(op, rb0, rb1, 1, op.nct, X, ldx, Y, ldy, ncols, nullptr, s);
   }
   SAPCA_HIP(hipGetLastError());
 }

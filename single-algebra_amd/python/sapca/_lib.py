@@ -35,7 +35,7 @@ class Timings(C.Structure):
         ("n_spmm", C.c_uint32), ("n_spmmt", C.c_uint32),
         ("spmm_sweep_ms", C.c_double * 32), ("spmmt_sweep_ms", C.c_double * 32),
         ("bytes_per_sweep", C.c_double), ("lanczos_steps", C.c_uint64),
-        ("sweep_kernel", C.c_uint32), ("reserved0", C.c_uint32), ("sweep_slots_a", C.c_uint64), ("sweep_slots_at", C.c_uint64),
+        ("sweep_kernel", C.c_uint32), ("at_sweep_pieces", C.c_uint32), ("sweep_slots_a", C.c_uint64), ("sweep_slots_at", C.c_uint64),
     ]
 
 

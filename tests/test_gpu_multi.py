@@ -84,3 +84,30 @@ def test_a_failing_shard_fails_the_call_and_releases_its_peers():
     with pytest.raises(L.SapcaError, match="mask vector length"):
         sapca.MultiDevice(sapca.MaskedSparsePCABuilder.new().n_components(2).mask(np.ones(n + 1, bool))
                           .svd_method(SVDMethod.Random(3, 1)).build(), [0, 0]).fit(B)
+
+
+def test_transposed_sweep_in_two_pieces_with_the_first_all_reduce_behind_the_second(monkeypatch):
+    """the n x l panel of an A^T sweep is the one bandwidth-relevant collective of a sharded fit.  Where the
+    operator allows it (DPP-fed sweep, rows in natural order) the sweep runs in two pieces of its output rows and the first
+    piece's all-reduce runs on a side stream behind the second piece's sweep; the members agree on the cut (their own row
+    blocks differ).  Same fit as with SAPCA_AT_OVERLAP=0 to f32 rounding, and the timings say which path ran."""
+    m, n, k, p, q = 7000, 2600, 10, 6, 2
+    A = _host(m, n, 0.05, k, 13, torch.float32)
+    om = synth.gaussian_panel(n, k + p, 5).numpy()
+    monkeypatch.setenv("SAPCA_NO_ROWSORT", "1")            # natural row order: a piece's rows are a contiguous range of the panel
+    make = lambda: (sapca.SparsePCABuilder.new().n_components(k).spmm_variant(2).collect_timings(True)
+                    .svd_method(SVDMethod.Random(p, q, PIN.QR)).build())
+    res = {}
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("SAPCA_AT_OVERLAP", overlap)
+        md = sapca.MultiDevice(make(), [0, 0]).set_omega(om)
+        t = md.fit_transform(A)
+        pieces = [int(md.member(i).timings().at_sweep_pieces) for i in range(2)]
+        assert pieces == ([2, 2] if overlap == "1" else [1, 1]), pieces
+        res[overlap] = (md.singular_values_(np.float64), md.components_(np.float64), t)
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=1e-5)
+    assert O.subspace_angle(res["1"][1], res["0"][1]) < 1e-5
+    np.testing.assert_allclose(res["1"][2], res["0"][2], atol=1e-4 * np.abs(res["0"][2]).max())
+    one = make().set_omega(om)
+    one.fit(A)
+    assert O.subspace_angle(res["1"][1], one.components_(np.float64)) < 2e-5
