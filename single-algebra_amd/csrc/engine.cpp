@@ -99,6 +99,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   if (h.stream3) SAPCA_HIP(hipStreamSynchronize(h.stream3));
   h.stats_pending = false;
   h.stats_on_side = false;
+  h.lz_scatter = false;
 
   // LDS-staged sweep (f32, randomized): decided here because it fixes the order in which the transposed
   // rows are produced.  It refills an 80 KiB panel tile per (row block, column tile) chunk and only beats
@@ -173,6 +174,27 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     }
   }
 
+  // Lanczos fits whose transposed side fits a workgroup's LDS (at most ~19k kept columns: C3 keeps 18k) never build A^T: the
+  // second product of a step scatters into LDS (scatter.hip, fixed-point sums: reproducible) and the column statistics
+  // come from the same kind of pass over A, on the third stream beside the iterations (a Lanczos fit does not centre:
+  // nothing reads them before fit() ends).  What is left of the preparation is the mask compaction.
+  // SAPCA_LANCZOS_TRANSPOSE=1 brings the transposed operator (radix sort) back.
+  const bool serial_early = getenv("SAPCA_PREPARE_SERIAL") != nullptr;
+  bool lz_scatter = h.opt.method == SAPCA_LANCZOS && n_used > 0 && n_used <= m && m >= 4096 && nnz > 0 && k::scatter_fits(n_used) &&
+                    (!masked || !serial_early) && getenv("SAPCA_LANCZOS_TRANSPOSE") == nullptr;
+  bool lz_side = false;   // its statistics run on the third stream
+  if (lz_scatter) {
+    unsigned long long* sc = h.lz_scalars.as<unsigned long long>(4);   // max |a| ; max |y| of even / odd steps
+    k::absmax(A.val, nnz, sc, s);
+    unsigned long long bits = 0;
+    SAPCA_HIP(hipMemcpyAsync(&bits, sc, sizeof(bits), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+    double amax;
+    std::memcpy(&amax, &bits, sizeof(amax));
+    lz_scatter = std::isfinite(amax);   // (inf / nan among the values: the floating-point route carries them through)
+  }
+  h.lz_scatter = lz_scatter;
+
   // A's side of the preparation runs beside the main stream.  Its pieces synchronise with the host (entry counts come
   // back), so where the main thread has its own synchronising work a helper thread drives them on the side stream:
   //  * masked fits: the column compaction (MaskedCSRMatrix::new, sparse_masked/mod.rs:313), then the compacted matrix's format;
@@ -202,12 +224,12 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
     int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    drop_col = from_upload ? nullptr : h.drop_col.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
-    drop_val = from_upload ? nullptr : h.drop_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    drop_col = (from_upload || lz_scatter) ? nullptr : h.drop_col.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    drop_val = (from_upload || lz_scatter) ? nullptr : h.drop_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
     k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val);
     h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
     compaction_done = true;
-    if (!from_upload) {
+    if (!from_upload && !lz_scatter) {
       // the masked-out columns' sums on their own stream, beside the transposition / the bucket route of the kept part and
       // A's format build (sum | sumsq of every column, zero where a column is kept).  Single-rank fits (`side_stats`) keep
       // them in their own arrays and never wait for them on the main stream: see the statistics below.
@@ -315,7 +337,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   // masked, off the bucket route: the compacted matrix transposed into a CSR (tile-major rows where the staged sweep's format
   // is built from them), the kept columns' sums as its row sums, the masked-out columns' from the dropped pairs
   bool masked_compact = false;
-  if (compaction_done && !masked_direct) {
+  if (compaction_done && !masked_direct && !lz_scatter) {
     Scope sc(h, C_PREPARE);
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
     int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
@@ -347,7 +369,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     SAPCA_HIP(hipStreamWaitEvent(h.stream2, h.ev_fork, 0));
   }
 
-  if (!at_direct && !masked_direct && !masked_compact) {
+  if (!at_direct && !masked_direct && !masked_compact && !lz_scatter) {
     Scope sc(h, C_PREPARE);
     int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
     int32_t* at_idx = h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
@@ -375,6 +397,27 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
     if (uploaded) {
       SAPCA_HIP(hipMemcpyAsync(d_stats, h.up_stats.out.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    } else if (lz_scatter) {
+      // every column of A (masked-out ones included: mean_ is full width, sparse_masked/mod.rs:279-286) straight from A
+      const unsigned long long* sc = h.lz_scalars.ptr<unsigned long long>();
+      if (!h.comm.active()) {
+        // one rank: on the third stream, with the copy to the host behind it; fit() waits for ev_stats at its end
+        if (!h.stream3) {
+          SAPCA_HIP(hipStreamCreateWithFlags(&h.stream3, hipStreamNonBlocking));
+          SAPCA_HIP(hipEventCreateWithFlags(&h.ev_kept, hipEventDisableTiming));
+          SAPCA_HIP(hipEventCreateWithFlags(&h.ev_stats, hipEventDisableTiming));
+        }
+        SAPCA_HIP(hipEventRecord(h.ev_kept, s));   // (A and max |a| are in place on the main stream)
+        SAPCA_HIP(hipStreamWaitEvent(h.stream3, h.ev_kept, 0));
+        k::colstats_scatter(A, sc, d_stats, d_stats + n, d_stats + 2 * n, h.drop_tmp, h.stream3);
+        SAPCA_HIP(hipMemcpyAsync(sums, d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, h.stream3));
+        SAPCA_HIP(hipEventRecord(h.ev_stats, h.stream3));
+        sums[(size_t)2 * n] = (double)m;
+        h.stats_on_side = true;
+        lz_side = true;
+        return;
+      }
+      k::colstats_scatter(A, sc, d_stats, d_stats + n, d_stats + 2 * n, h.scratch, s);
     } else if (at_direct) {
       k::row_lengths_f64(At.ptr, n, d_stats + 2 * n, s);   // (the sums came out of the format build)
     } else if (masked_direct || masked_compact) {
@@ -421,7 +464,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
 
   // operator seen by the SVD engines: MaskedCSRMatrix::new (sparse_masked/mod.rs:313)
   int64_t nnz_used_t = 0;
-  if (masked_direct || masked_compact) {
+  if (lz_scatter) {
+    // no transposed operator: a_used is A or its compaction (set above), at_used only carries the shape
+    if (!masked) { h.a_used = {m, n, nnz, A.ptr, A.idx, A.val}; nnz_used = nnz; }
+    SAPCA_CHECK(!masked || compaction_done, SAPCA_ERR_HIP, "internal: Lanczos scatter route without its compaction");
+    h.at_used = {n_used, m, nnz_used, nullptr, nullptr, nullptr};
+    nnz_used_t = nnz_used;
+  } else if (masked_direct || masked_compact) {
     nnz_used_t = nnz_used;   // (a_used and at_used were set above)
   } else if (masked) {
     Scope sc(h, C_PREPARE);
@@ -502,7 +551,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   join_aside();   // (fits without tile-major formats)
   if (a_built_aside) SAPCA_HIP(hipStreamWaitEvent(s, h.ev_join, 0));
 
-  if (h.stats_on_side) {
+  if (h.stats_on_side && !lz_side) {
     // everything the first sweep needs is queued: now the masked-out columns' sums, the kept columns' sums over them, the
     // copy of all statistics to the host (read at the end of fit())
     double* d_stats = h.stats.ptr<double>();
@@ -840,16 +889,28 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
   SAPCA_CHECK(h.m_global >= 2, SAPCA_ERR_ARG, "need at least two samples");
 
   // column means of the features the SVD sees, in T (the centring vector of the sweeps and of transform)
-  {
+  auto device_means = [&] {
     T* d_mu = h.mean_used_dev.as<T>((size_t)n_used);
     if (h.opt.center)
       k::mean_from_sums(h.stats.ptr<double>(), (double)h.m_global, h.has_mask_maps ? h.sel_rows_dev.ptr<int32_t>() : nullptr, n_used, d_mu, s);
     else
       SAPCA_HIP(hipMemsetAsync(d_mu, 0, (size_t)n_used * sizeof(T), s));
-  }
+  };
 
-  if (h.opt.method == SAPCA_RANDOM) fit_randomized(h);
-  else fit_lanczos(h);
+  if (h.opt.method == SAPCA_RANDOM) {
+    device_means();
+    fit_randomized(h);
+  } else {
+    // the Lanczos branch never centres (Q1): only transform reads the means.  On the scatter route the column sums arrive
+    // from the third stream, beside the iterations: the main stream meets them here, behind the last step
+    const bool sums_on_side = h.lz_scatter && h.stats_on_side;
+    if (!sums_on_side) device_means();
+    fit_lanczos(h);
+    if (sums_on_side) {
+      SAPCA_HIP(hipStreamWaitEvent(s, h.ev_stats, 0));
+      device_means();
+    }
+  }
 
   h.k = h.opt.n_components;
   h.n_used = (uint64_t)n_used;

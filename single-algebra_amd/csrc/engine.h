@@ -60,6 +60,7 @@ struct sapca_handle_s {
   std::vector<double> prep_mean;  // column means of the prepared matrix (n)
   double prep_total_var = 0;
   uint32_t at_sweep_pieces = 1;   // 2: the last randomized fit swept A^T in two pieces (multi-rank overlap)
+  bool lz_scatter = false;        // the prepared Lanczos fit has no transposed operator: its second product scatters into LDS (scatter.hip)
   bool q3_cancels = false;        // a kept column is well filled and of small spread: the masked projection subtracts entry by entry
   // the column sums on the host (sum | sumsq | row count), copied asynchronously: single-rank fits read them at the end
   // of fit() instead of stalling the stream between the preparation and the first sweep
@@ -97,7 +98,7 @@ struct sapca_handle_s {
   sapca::DevBuf idx16_a, idx16_b;                                 // 2-byte index copies of the two operators of a Lanczos step
   sapca::TiledBuffers tb_a, tb_at;                               // tile-major formats for the LDS-staged sweep
   sapca::TiledOp tiled_a, tiled_at;
-  sapca::DevBuf split_scratch, split_scratch2, votes;
+  sapca::DevBuf split_scratch, split_scratch2, votes, lz_scalars;
 
   sapca::EventTimer timer;
   std::vector<std::pair<int, int>> spans;  // (category, event index) of the last fit/transform

@@ -86,6 +86,23 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
 template <typename T>
 void spmm_rows_shifted(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, int ncols, const T* shift, hipStream_t s);
 
+// ---- scatter.hip: column-wise reductions of a CSR without its transpose (fixed-point sums in LDS) ----------
+bool scatter_fits(int64_t cols);   // one output vector of `cols` 64-bit words fits a workgroup's LDS
+// *out_bits = bit pattern of max |v| as a double (a quiet NaN's pattern if any value is inf / nan)
+template <typename T>
+void absmax(const T* v, int64_t count, unsigned long long* out_bits, hipStream_t s);
+// *out_bits = max(*out_bits, max |y|): the slot must have been cleared
+void vecmax(const double* y, int64_t len, unsigned long long* out_bits, hipStream_t s);
+// z = A^T y  (A: rows x cols, cols fitting LDS).  amax_bits / ymax_bits: max |a|, max |y| (the fixed-point scale follows from
+// them); clear_bits (nullable): a slot to reset to 0 for the next product.  idx16 (nullable): 2-byte copy of A.idx.
+template <typename T>
+void spmvt_scatter(const CsrView<T>& A, const uint16_t* idx16, const double* y, const unsigned long long* amax_bits,
+                   const unsigned long long* ymax_bits, unsigned long long* clear_bits, double* z, DevBuf& scratch, hipStream_t s);
+// sum[c], sumsq[c], cnt[c] (nullable) of every column of A in ceil(cols / 7680) passes over the matrix
+template <typename T>
+void colstats_scatter(const CsrView<T>& A, const unsigned long long* amax_bits, double* sum, double* sumsq, double* cnt, DevBuf& scratch,
+                      hipStream_t s);
+
 // ---- spmm_tiled.hip ---------------------------------------------------------------------
 // Builds the tile-major format of an f32 operator for panels of leading dimension ldp (64/128).
 // Returns false (op.valid == false) when the operator does not fit the LDS staging; callers then

@@ -523,11 +523,27 @@ void lanczos_fit(sapca_handle_s& h) {
   hipLaunchKernelGGL(norm2_kernel, dim3(nparts), dim3(256), 0, s, w, len, partial);
   hipLaunchKernelGGL(scale_kernel, dim3(grid1(len, 256, 1024)), dim3(256), 0, s, w, len, partial, nparts, beta + jmax + 1, V);
 
+  // No transposed operator (prepare() took the scatter route: the transposed side fits LDS): the second product of a step
+  // scatters A's rows into per-workgroup fixed-point copies of the output (scatter.hip) -- same bytes read as a gather
+  // along A^T's rows, no transposition before the first step.
+  const bool scatter = h.lz_scatter;
+  SAPCA_CHECK(!scatter || (right_side && At.ptr == nullptr), SAPCA_ERR_HIP, "internal: Lanczos scatter route on the wrong side");
+  SAPCA_CHECK(scatter || At.ptr != nullptr || At.nnz == 0, SAPCA_ERR_HIP, "internal: Lanczos without a transposed operator");
+  unsigned long long* sc = scatter ? h.lz_scalars.ptr<unsigned long long>() : nullptr;   // max |a| (prepare) ; max |y| of even / odd products
+  if (scatter) SAPCA_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(unsigned long long), s));
+  int64_t product = 0;
   // 2-byte index copies for the two products of a step (one pass over the indices each, paid back in a few steps)
   const uint16_t* first16 = spmv_narrow_indices(right_side ? A : At, false, h.idx16_a, s);
-  const uint16_t* second16 = spmv_narrow_indices(right_side ? At : A, true, h.idx16_b, s);
+  const uint16_t* second16 = scatter ? nullptr : spmv_narrow_indices(right_side ? At : A, true, h.idx16_b, s);
   auto apply_B = [&](const double* v, double* out) {  // out = A^T A v  (or A A^T v)
-    if (right_side) {
+    if (scatter) {
+      spmv_launch(A, v, tmp, s, nullptr, first16);
+      unsigned long long* ymax = sc + 1 + (product & 1), *next = sc + 1 + ((product + 1) & 1);
+      ++product;
+      k::vecmax(tmp, other, ymax, s);
+      k::spmvt_scatter(A, first16, tmp, sc, ymax, next, out, h.scratch2, s);   // (the same 2-byte indices: one copy serves both products)
+      if (h.comm.active()) h.comm.allreduce(out, (uint64_t)len, 1, s);
+    } else if (right_side) {
       spmv_launch(A, v, tmp, s, nullptr, first16);
       spmv_launch(At, tmp, out, s, &h.scratch2, second16);
       if (h.comm.active()) h.comm.allreduce(out, (uint64_t)len, 1, s);
