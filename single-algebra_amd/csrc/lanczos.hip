@@ -65,8 +65,9 @@ spmv_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, co
 template <typename T, typename I>
 __global__ void __launch_bounds__(1024)
 spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const I* __restrict__ idx, const T* __restrict__ val, int64_t rows,
-                 int64_t cols, const double* __restrict__ x, double* __restrict__ y) {
+                 int64_t cols, const double* __restrict__ x, double* __restrict__ y, unsigned long long* __restrict__ ymax_bits) {
   extern __shared__ double xs[];
+  double ymax = 0.0;   // (lane 0 of every wave: the largest |y| it wrote, for the fixed-point scale of the scatter product that follows)
   for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) xs[i] = x[i];
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
@@ -91,7 +92,9 @@ spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const I* __restrict__ idx, con
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) a0 += __shfl_xor(a0, off);
     if (lane == 0) y[r] = a0;
+    ymax = fmax(ymax, fabs(a0));
   }
+  if (ymax_bits && lane == 0) atomicMax(ymax_bits, (unsigned long long)__double_as_longlong(ymax));   // non-negative doubles order like integers
 }
 
 // Long x (A^T y: x has one element per sample): x is cut into slices that fit LDS and a workgroup walks its
@@ -413,7 +416,8 @@ const uint16_t* spmv_narrow_indices(const CsrView<T>& A, bool has_scratch, DevBu
 
 template <typename T>
 void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s, DevBuf* scratch = nullptr,
-                 const uint16_t* idx16 = nullptr) {
+                 const uint16_t* idx16 = nullptr, unsigned long long* ymax_bits = nullptr, bool* ymax_done = nullptr) {
+  if (ymax_done) *ymax_done = false;   // (only the kernel with x in LDS gathers max |y| on the way)
   if (A.rows == 0) return;
   const size_t xbytes = (size_t)A.cols * sizeof(double);
   static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
@@ -421,11 +425,12 @@ void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s,
     static LdsAttrState attr, attr16;   // one per instantiation of this function template
     if (idx16) {
       ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T, uint16_t>), 150 * 1024, attr16);
-      hipLaunchKernelGGL((spmv_ldsx_kernel<T, uint16_t>), dim3(256), dim3(1024), xbytes, s, A.ptr, idx16, A.val, A.rows, A.cols, x, y);
+      hipLaunchKernelGGL((spmv_ldsx_kernel<T, uint16_t>), dim3(256), dim3(1024), xbytes, s, A.ptr, idx16, A.val, A.rows, A.cols, x, y, ymax_bits);
     } else {
       ensure_dynamic_lds(reinterpret_cast<const void*>(&spmv_ldsx_kernel<T, int32_t>), 150 * 1024, attr);
-      hipLaunchKernelGGL((spmv_ldsx_kernel<T, int32_t>), dim3(256), dim3(1024), xbytes, s, A.ptr, A.idx, A.val, A.rows, A.cols, x, y);
+      hipLaunchKernelGGL((spmv_ldsx_kernel<T, int32_t>), dim3(256), dim3(1024), xbytes, s, A.ptr, A.idx, A.val, A.rows, A.cols, x, y, ymax_bits);
     }
+    if (ymax_done) *ymax_done = ymax_bits != nullptr;
     return;
   }
   if (!no_lds && A.nnz >= 256 * A.rows && A.rows >= 1024) {   // long rows: slices of x through LDS
@@ -537,10 +542,11 @@ void lanczos_fit(sapca_handle_s& h) {
   const uint16_t* second16 = scatter ? nullptr : spmv_narrow_indices(right_side ? At : A, true, h.idx16_b, s);
   auto apply_B = [&](const double* v, double* out) {  // out = A^T A v  (or A A^T v)
     if (scatter) {
-      spmv_launch(A, v, tmp, s, nullptr, first16);
       unsigned long long* ymax = sc + 1 + (product & 1), *next = sc + 1 + ((product + 1) & 1);
       ++product;
-      k::vecmax(tmp, other, ymax, s);
+      bool have_max = false;
+      spmv_launch(A, v, tmp, s, nullptr, first16, ymax, &have_max);
+      if (!have_max) k::vecmax(tmp, other, ymax, s);
       k::spmvt_scatter(A, first16, tmp, sc, ymax, next, out, h.scratch2, s);   // (the same 2-byte indices: one copy serves both products)
       if (h.comm.active()) h.comm.allreduce(out, (uint64_t)len, 1, s);
     } else if (right_side) {

@@ -90,16 +90,30 @@ spmvt_scatter_kernel(const int64_t* __restrict__ ptr, const I* __restrict__ idx,
   for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) out[i] = zs[i];
 }
 
-// z[c] = (sum over the workgroups of part[.][c]) / scale; the slot of the NEXT step's max|y| is cleared on the way
-__global__ void __launch_bounds__(256)
+// z[c] = (sum over the workgroups of part[.][c]) / scale; the slot of the NEXT step's max|y| is cleared on the way.
+// A workgroup takes 64 columns, its 16 waves a sixteenth of the copies each (16 independent loads in flight per thread).
+__global__ void __launch_bounds__(1024)
 spmvt_reduce_kernel(const long long* __restrict__ part, int nparts, int64_t rows, int64_t cols, const unsigned long long* __restrict__ amax_bits,
                     const unsigned long long* __restrict__ ymax_bits, unsigned long long* __restrict__ clear_bits, double* __restrict__ z) {
+  __shared__ long long acc[16][64];
   const double scale = fixed_scale((double)rows * bits_to_double(*amax_bits) * bits_to_double(*ymax_bits));
   const double inv = scale > 0.0 ? 1.0 / scale : 0.0;   // (a power of two: exact)
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
-    long long a = 0;
-    for (int p = 0; p < nparts; ++p) a += part[(int64_t)p * cols + c];
-    z[c] = (double)a * inv;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (nparts + 15) / 16;
+  long long a = 0;
+  if (c < cols) {
+    const int p1 = min(nparts, (grp + 1) * per);
+#pragma unroll 16
+    for (int p = grp * per; p < p1; ++p) a += part[(int64_t)p * cols + c];
+  }
+  acc[grp][lane] = a;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+    long long t = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += acc[g][lane];
+    z[c] = (double)t * inv;
   }
   if (clear_bits && blockIdx.x == 0 && threadIdx.x == 0) *clear_bits = 0ull;
 }
@@ -153,24 +167,41 @@ colstats_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 colstats_reduce_kernel(const long long* __restrict__ part_sum, const long long* __restrict__ part_sq, const unsigned int* __restrict__ part_cnt,
                        int nparts, int64_t rows, int c0, int nc, const unsigned long long* __restrict__ amax_bits, double* __restrict__ sum,
                        double* __restrict__ sumsq, double* __restrict__ cnt) {
+  __shared__ long long sa[16][64], sb[16][64];
+  __shared__ unsigned long long sn[16][64];
   const double amax = bits_to_double(*amax_bits);
   const double s1 = fixed_scale((double)rows * amax), s2 = fixed_scale((double)rows * amax * amax);
   const double i1 = s1 > 0.0 ? 1.0 / s1 : 0.0, i2 = s2 > 0.0 ? 1.0 / s2 : 0.0;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
-    long long a = 0, b = 0;
-    unsigned long long n = 0;
-    for (int p = 0; p < nparts; ++p) {
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int per = (nparts + 15) / 16;
+  long long a = 0, b = 0;
+  unsigned long long n = 0;
+  if (c < nc) {
+    const int p1 = min(nparts, (grp + 1) * per);
+#pragma unroll 8
+    for (int p = grp * per; p < p1; ++p) {
       a += part_sum[(int64_t)p * nc + c];
       b += part_sq[(int64_t)p * nc + c];
       n += part_cnt[(int64_t)p * nc + c];
     }
-    sum[c0 + c] = (double)a * i1;
-    sumsq[c0 + c] = (double)b * i2;
-    if (cnt) cnt[c0 + c] = (double)n;
+  }
+  sa[grp][lane] = a;
+  sb[grp][lane] = b;
+  sn[grp][lane] = n;
+  __syncthreads();
+  if (grp == 0 && c < nc) {
+    long long ta = 0, tb = 0;
+    unsigned long long tn = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { ta += sa[g][lane]; tb += sb[g][lane]; tn += sn[g][lane]; }
+    sum[c0 + c] = (double)ta * i1;
+    sumsq[c0 + c] = (double)tb * i2;
+    if (cnt) cnt[c0 + c] = (double)tn;
   }
 }
 
@@ -211,8 +242,8 @@ void spmvt_scatter(const CsrView<T>& A, const uint16_t* idx16, const double* y, 
     hipLaunchKernelGGL((spmvt_scatter_kernel<T, int32_t>), dim3(kParts), dim3(SC_THREADS), lds, s, A.ptr, A.idx, A.val, A.rows, A.cols, y, amax_bits,
                        ymax_bits, part);
   }
-  hipLaunchKernelGGL(spmvt_reduce_kernel, dim3((unsigned)std::min<int64_t>((A.cols + 255) / 256, 256)), dim3(256), 0, s, part, kParts, A.rows, A.cols,
-                     amax_bits, ymax_bits, clear_bits, z);
+  hipLaunchKernelGGL(spmvt_reduce_kernel, dim3((unsigned)((A.cols + 63) / 64)), dim3(1024), 0, s, part, kParts, A.rows, A.cols, amax_bits, ymax_bits,
+                     clear_bits, z);
   SAPCA_HIP(hipGetLastError());
 }
 
@@ -235,7 +266,7 @@ void colstats_scatter(const CsrView<T>& A, const unsigned long long* amax_bits, 
     if (nc <= 0) break;
     hipLaunchKernelGGL((colstats_scatter_kernel<T>), dim3(kParts), dim3(SC_THREADS), (size_t)nc * per_col, s, A.ptr, A.idx, A.val, A.rows, c0, nc,
                        amax_bits, ps, pq, pc);
-    hipLaunchKernelGGL(colstats_reduce_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ps, pq, pc, kParts, A.rows, c0, nc, amax_bits, sum,
+    hipLaunchKernelGGL(colstats_reduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(1024), 0, s, ps, pq, pc, kParts, A.rows, c0, nc, amax_bits, sum,
                        sumsq, cnt);
   }
   SAPCA_HIP(hipGetLastError());
