@@ -487,8 +487,8 @@ def _random_case(seed):
     rng = np.random.default_rng(1000 + seed)
     k = int(rng.integers(1, 13))
     # at least 60 rows and 40 columns per planted cluster: smaller blocks drown in the background entries
-    m = int(rng.integers(60 * (k + 1), 60 * (k + 1) + 2500))
-    n = int(rng.integers(40 * (k + 1), 40 * (k + 1) + 1300))
+    m = int(rng.integers(60 * (k + 1), 60 * (k + 1) + 1500))   # (sizes bounded by the dense SVD that certifies the gap)
+    n = int(rng.integers(40 * (k + 1), 40 * (k + 1) + 700))
     return dict(
         m=m, n=n, k=k, dens=float(rng.uniform(0.04, 0.3)), p=int(rng.integers(1, 9)), q=int(rng.integers(0, 4)),
         norm=[PIN.QR, PIN.LU, PIN.NONE][int(rng.integers(0, 3))], center=bool(rng.integers(0, 2)), masked=bool(rng.integers(0, 2)),
