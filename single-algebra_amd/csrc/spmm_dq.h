@@ -5,6 +5,14 @@
 namespace sapca {
 namespace k {
 
+// Steps of a quad in a tile = its longest row segment, rounded up to an even count unless the build lets quads end on any
+// step (-DSAPCA_ODD_STEPS: the DPP-fed sweep's main loop is then generated with DQ2_ODD=1 and counts per step).
+#ifdef SAPCA_ODD_STEPS
+constexpr bool kOddSteps = true;
+#else
+constexpr bool kOddSteps = false;
+#endif
+
 // Per (row block, wave, tile) stream offsets / chunk counts and the per-two-step row-slot descriptors of a built
 // quad-format operator.  Returns false (op.dq stays false) when the operator is not eligible: the callers then use
 // the staged-entry quad sweep.

@@ -43,6 +43,8 @@ constexpr int DQ_WAVES = 16, DQ_THREADS = DQ_WAVES * WAVE;
 constexpr int DQ_BLOCK_QUADS = 256;           // stride of the per-chunk quad step table (= Q_BLOCK_QUADS of spmm_tiled.hip)
 constexpr int DQ_TILE_BYTES = DQ2_TILE_BYTES;
 constexpr int DQ_LDS = 2 * DQ_TILE_BYTES;
+static_assert((DQ2_ODD_STEPS != 0) == kOddSteps, "the generated main loop and the format disagree on odd step counts (DQ2_ODD / -DSAPCA_ODD_STEPS)");
+constexpr int DQ_OFF_UNIT = kOddSteps ? 4 : 8;   // entries per unit of a stream's offset in the info table
 static_assert(DQ2_ACC_BASE == 56, "the accumulator operands below are written out for row slots starting at v56");
 
 __host__ __device__ inline int dq_first(int wave, int nquads) { return wave * nquads / DQ_WAVES; }
@@ -78,7 +80,7 @@ dq_info_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __r
     if (lane < DQ_WAVES) {
       const int64_t s = chunk_off[cidx] + (int64_t)wave_off[cidx * DQ_WAVES + wave];
       uint32_t* w = info + (((int64_t)rb * DQ_WAVES + wave) * nct + t) * 2;
-      w[0] = (uint32_t)(s / 8);
+      w[0] = (uint32_t)(s / DQ_OFF_UNIT);
       w[1] = (uint32_t)((n + 15) / 16) | ((uint32_t)rank << 16);
     }
   }
@@ -187,7 +189,7 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   static const bool off = getenv("SAPCA_NO_DQ") != nullptr;
   if (off || !op.valid || op.elem != 4 || op.fmt != 1 || op.ldp != 64 || op.tile_bytes != DQ_TILE_BYTES) return false;
   if (op.block_rows != 512 && op.block_rows != 1024) return false;
-  if (op.total_entries / 8 >= (int64_t)1 << 32) return false;
+  if (op.total_entries / DQ_OFF_UNIT >= (int64_t)1 << 32) return false;
   const int64_t nchunks = (int64_t)op.nrb * op.nct;
   const size_t info_words = ((size_t)nchunks * DQ_WAVES + 64) * 2;   // (+ a 64-tile window of slack: the sweep loads whole windows)
   uint32_t* d_info = buf.dq_info.as<uint32_t>(info_words);

@@ -397,7 +397,7 @@ constexpr int ENT_SLACK = 4 * WAVE;             // zero entries behind the last 
 constexpr int q_rows_per_group(int ldp) { return (ldp == 64 ? 128 : 64) / QWAVES; }
 // steps of a quad in a tile: its longest row segment, rounded up to an even count (the DPP-fed sweep of spmm_dq.hip
 // switches row slots every two steps)
-__host__ __device__ inline int q_steps(int longest) { return (longest + 1) & ~1; }
+__host__ __device__ inline int q_steps(int longest) { return kOddSteps ? longest : (longest + 1) & ~1; }
 // quads (4 consecutive rows) of a block are dealt to its 16 waves in contiguous, balanced ranges
 __host__ __device__ inline int q_first(int wave, int nquads) { return wave * nquads / QWAVES; }
 

@@ -46,6 +46,7 @@ VA64 = 30         # v[30:31]: 64-bit source address of an LDS-DMA piece
 W = [[32, 36], [40, 44]]
 VCNT, VCNT2 = 48, 49   # two-step groups - 1 of this wave's quads in the current tile (lane j = quad j; -1: none); raw step counts of the next
 DEPTH = int(os.environ.get("DQ2_DEPTH", "2"))   # two-step groups in flight per wave (3: a third register set behind the accumulators)
+ODD = os.environ.get("DQ2_ODD", "0") != "0"     # quads of any step count (the format no longer rounds a quad's steps up to even): the counter runs per step
 PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from the info table
 ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved with the next group's DPP instructions, reads last
 # experiment switches (environment, read when the header is generated)
@@ -190,8 +191,8 @@ def dma_piece(L):
 
 def ptr_from_off8(L, s_off8, dst, base):
     """s[dst:dst+1] = base (64-bit operand name) + 64 * s_off8   (s_off8: entry offset in units of 8 entries)"""
-    L.append(f"s_lshl_b32 s{S_CC}, s{s_off8}, 6")
-    L.append(f"s_lshr_b32 s{S_D}, s{s_off8}, 26")
+    L.append(f"s_lshl_b32 s{S_CC}, s{s_off8}, {5 if ODD else 6}")   # (ODD: streams start at multiples of 4 entries, 32 bytes)
+    L.append(f"s_lshr_b32 s{S_D}, s{s_off8}, {27 if ODD else 26}")
     L.append(f"s_mov_b64 s[{dst}:{dst + 1}], %[{base}]")
     L.append(f"s_add_u32 s{dst}, s{dst}, s{S_CC}")
     L.append(f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}")
@@ -207,14 +208,21 @@ def set_ret(L, s):
 
 def bodies(L):
     """RG copies of a chunk's eight two-step groups.  Position k of slot s: the FMAs of group k into slot s's accumulators,
-    then group k + 2 issued; the quad's counter; fall through to position k + 1 (position 7: the chunk routine)."""
+    then group k + 2 issued; the quad's counter; fall through to position k + 1 (position 7: the chunk routine).
+    ODD: the counter runs per step, so a quad may hand over between the two steps of a group (body_s_k_mid)."""
     for s in range(RG):
         for k in range(8):
             L.append(f"body_{s}_{k}:")
             ahead = min(DEPTH, 8 - k) - 1
             L.append(f"s_waitcnt lgkmcnt({2 * ahead})")
             f0, f1 = grp_fma_parts(s, k)
-            if k + DEPTH < 8 and ILV and not B64:
+            if ODD:
+                L += f0
+                L += [f"s_sub_u32 s{S_C}, s{S_C}, 1", f"s_cbranch_scc1 landm_{s + 1}_{k}", f"body_{s}_{k}_mid:"]
+                L += f1
+                if k + DEPTH < 8:
+                    grp_a(k + DEPTH, L)
+            elif k + DEPTH < 8 and ILV and not B64:
                 # the two steps' FMAs go to the same accumulators: the next group's address / value instructions between them
                 adds, movs, reads = grp_a_parts(k + DEPTH)
                 L += f0 + adds + f1 + movs + reads
@@ -242,6 +250,16 @@ def stubs(L):
                 L.append(f"s_branch body_{s}_{k + 1}")
             else:
                 L.append(f"s_setpc_b64 s[{S_CTL}:{S_CTL + 1}]")
+    if ODD:   # the same hand-over between the two steps of group k
+        for k in range(8):
+            for s in range(1, RG + 1):
+                L.append(f"landm_{s}_{k}:")
+                if s == RG:
+                    L.append("s_branch tile_done")
+                    continue
+                L += [f"v_readlane_b32 s{S_C}, v{VCNT}, {s}", f"s_cmp_lt_i32 s{S_C}, 0", f"s_cbranch_scc1 landm_{s + 1}_{k}"]
+                set_ret(L, s)
+                L.append(f"s_branch body_{s}_{k}_mid")
     # tile entry: the first non-empty quad, then the first chunk's routine
     L.append("enter_0:")
     L += [f"v_readlane_b32 s{S_C}, v{VCNT}, 0", f"s_cmp_lt_i32 s{S_C}, 0", "s_cbranch_scc1 land_1_7"]
@@ -347,7 +365,7 @@ def body(pattern):
     L += ["s_barrier"]
     # the step counts (issued before the last three entry loads of a linked predecessor); everything of a tile that loaded its own
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 cnt_pre", "s_waitcnt vmcnt(0)", "s_branch cnt_ok", "cnt_pre:", "s_waitcnt vmcnt(3)", "cnt_ok:"]
-    L += [f"v_lshrrev_b32 v{VCNT}, 1, v{VCNT2}", f"v_add_u32 v{VCNT}, -1, v{VCNT}", f"s_mov_b64 vcc, s[{S_QM}:{S_QM + 1}]",
+    L += [f"v_mov_b32 v{VCNT}, v{VCNT2}" if ODD else f"v_lshrrev_b32 v{VCNT}, 1, v{VCNT2}", f"v_add_u32 v{VCNT}, -1, v{VCNT}", f"s_mov_b64 vcc, s[{S_QM}:{S_QM + 1}]",
           f"v_cndmask_b32 v{VCNT}, -1, v{VCNT}, vcc"]
     # pieces of the next tile go to the other buffer (the last tile reloads itself: harmless)
     L += [f"s_add_u32 s{S_DROW}, s{S_TABS}, 1", f"s_min_u32 s{S_DROW}, s{S_DROW}, s{S_TLAST}", f"s_sub_u32 s{S_DLDS}, {TILE_B}, s{S_BUF}",
@@ -412,7 +430,7 @@ def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "single-algebra_amd", "csrc", "spmm_dq2_gen.h")
     with open(path, "w") as out:
         out.write("// generated by tools/gen_spmm_dq2.py -- do not edit; the generator documents the structure\n")
-        out.write(f"#define DQ2_ACC_BASE {ACC}\n#define DQ2_TILE_BYTES {TILE_B}\n")
+        out.write(f"#define DQ2_ACC_BASE {ACC}\n#define DQ2_TILE_BYTES {TILE_B}\n#define DQ2_ODD_STEPS {1 if ODD else 0}\n")
         for rg in (8, 16):   # 512-row and 1024-row blocks
             for pattern in (False, True):
                 RG = rg
