@@ -698,8 +698,11 @@ void Engine<T>::fit_randomized(H& h) {
   int piece_wgs = 240;
   h.at_sweep_pieces = 1u;
   if constexpr (sizeof(T) == 4) {
+    // Default: on for the callback / in-process transports (tested with two and three ranks), off for RCCL until the library's
+    // own RCCL binding has run with more than one rank on real hardware (two streams then issue on one communicator);
+    // SAPCA_AT_OVERLAP=1 / 0 forces it either way.
     const char* ov = getenv("SAPCA_AT_OVERLAP");   // (read per fit: the tests switch it)
-    const bool overlap_off = ov != nullptr && atoi(ov) == 0;
+    const bool overlap_off = ov != nullptr ? atoi(ov) == 0 : h.comm.mode == Comm::RCCL;
     if (h.comm.active() && !overlap_off && variant != 1) {
       // The pieces are whole row blocks of this rank's operator, and ranks cut their blocks differently (the block count
       // follows the shard's own tile count): the ranks agree on one row count -- the smallest first piece, 0 if any rank
