@@ -12,7 +12,7 @@ i0=idx[-1]-2
 t0=int(rows[i0]["Start_Timestamp"])
 seen=False
 for r in rows[i0:i0+70]:
-    seen = seen or "dq_desc" in r["Kernel_Name"]
+    seen = seen or "dq_info" in r["Kernel_Name"]
     st=(int(r["Start_Timestamp"])-t0)/1e3; du=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
     name=r["Kernel_Name"].replace("sapca::k::(anonymous namespace)::","").replace("void ","")[:46]
     print("%9.1f us  %8.1f us  q%s  %s" % (st,du,r.get("Queue_Id","?"),name))
