@@ -20,6 +20,8 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s);
 bool dq_usable(const TiledOp& op, int ldx);
 // flags: 8 = pattern mode (every stored non-zero value reads as 1)
 void launch_dq(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, hipStream_t s, int flags = 0);
+// the f64 operator (elem == 8): one 64-column pass
+void launch_dq_f64(const TiledOp& op, const double* X, int ldx, double* out, int ldo, int ncols, const double* cvec, hipStream_t s);
 // the same over row blocks [rb0, rb1) with a split of the tile range chosen by the caller (`out` then holds nsplit slabs of
 // op.rows x ldo when nsplit > 1, slab sp at out + sp * op.rows * ldo: rows keep their absolute positions)
 void launch_dq_blocks(const TiledOp& op, int rb0, int rb1, int nsplit, int tiles_per_split, const float* X, int ldx, float* out, int ldo,

@@ -182,13 +182,101 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
   }
 }
 
+
+// The same sweep for T = f64 (generic over T like the reference, /root/reference/src/dimred/pca/sparse/mod.rs:33-36): the f64
+// quad format of spmm_tiled.hip (16-byte entries {u32 tile byte offset, pad, f64 value}, blocks of <= 256 rows = four row
+// slots per lane group, tiles of 160 panel rows of 512 bytes), a lane holds columns 2q, 2q+1, 32+2q, 32+2q+1 of its row
+// (two ds_read_b128 256 bytes apart), four v_fma_f64 per step, the value broadcast as one 64-bit DPP move; an LDS-DMA piece
+// is two panel rows.  Main loop: DQ2_MAIN_ASM_F64 (tools/gen_spmm_dq2.py).
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
+static_assert(DQ2_F64_ACC_BASE == 80, "the accumulator operands below are written out for row slots starting at v80");
+constexpr int DQ_F64_RG = 4;
+
+__global__ void __launch_bounds__(DQ_THREADS)
+spmm_dq_f64_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct, const void* __restrict__ ent,
+                   const uint16_t* __restrict__ steps, const uint32_t* __restrict__ info, int64_t panel_rows, const double* __restrict__ X,
+                   int ldx, int nsplit, int tiles_per_split, double* __restrict__ out, int64_t out_rows_total, int ldo, int ncols,
+                   const double* __restrict__ cvec, int rb0) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
+  const int g = lane / 16, q = lane % 16;
+  const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
+  const int nquads = (nrows + 3) / 4;
+  const int quad0 = dq_first(wave, nquads), my_quads = dq_first(wave + 1, nquads) - quad0;   // <= 4
+  const int my_rows = min(nrows, 4 * (quad0 + my_quads)) - 4 * quad0;
+
+  v4d a0, a1, a2, a3, a4, a5, a6, a7;   // slot j: a(2j) = columns 2q, 2q+1 ; a(2j+1) = columns 32+2q, 32+2q+1
+  if (ct0 < ct1) {
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int half = lane / 32;   // which of a piece's two panel rows this lane brings
+    unsigned lb = lds_base + q * 16, eoff = q * 64 + g * 16, l8 = lane * 8, l2 = lane * 2, l2c = min(lane, 15) * 2, col16 = (lane & 31) * 16;
+    unsigned rowb0 = (unsigned)(2 * (wave * 5) + half) * (unsigned)nct;
+    const unsigned wdma = __builtin_amdgcn_readfirstlane(lds_base + wave * 5 * 1024);
+    const unsigned myq = __builtin_amdgcn_readfirstlane((unsigned)my_quads);
+    auto uniform64 = [](unsigned long long p) {
+      return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) << 32) |
+             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)p);
+    };
+    const unsigned long long ip = uniform64((unsigned long long)(info + (((int64_t)rb * DQ_WAVES + wave) * nct + ct0) * 2));
+    const unsigned long long stp = uniform64((unsigned long long)(steps + ((int64_t)rb * nct + ct0) * DQ_BLOCK_QUADS + quad0));
+    const unsigned xlo = (unsigned)(uintptr_t)X, xhi = (unsigned)((uintptr_t)X >> 32);
+    const unsigned stride = (unsigned)ldx * 8u;
+    const unsigned voff = (unsigned)half * (unsigned)nct * stride + col16;   // lane part of an LDS-DMA piece's source address
+    const unsigned prm1 = (unsigned)(panel_rows - 1), ntiles = (unsigned)(ct1 - ct0), t0 = (unsigned)ct0;
+    asm volatile(DQ2_MAIN_ASM_F64
+                 : "=&{v[80:87]}"(a0), "=&{v[88:95]}"(a2), "=&{v[96:103]}"(a4), "=&{v[104:111]}"(a6)
+                 : [ent] "s"(ent), [stp] "s"(stp), [xlo] "s"(xlo), [xhi] "s"(xhi), [info] "s"(ip), [lb] "v"(lb), [eoff] "v"(eoff), [l8] "v"(l8),
+                   [l2] "v"(l2), [l2c] "v"(l2c), [col16] "v"(col16), [rowb0] "v"(rowb0), [nct] "s"(nct), [stride] "s"(stride), [prm1] "s"(prm1),
+                   [ntiles] "s"(ntiles), [t0] "s"(t0), [wdma] "s"(wdma), [myq] "s"(myq), [voff] "v"(voff)
+                 : DQ2_MAIN_CLOBBERS_F64);
+  } else {
+    a0 = a2 = a4 = a6 = v4d(0.0);
+  }
+  (void)a1; (void)a3; (void)a5; (void)a7;
+  // slot j sits in a(2j) as {col 2q, col 2q+1, col 32+2q, col 32+2q+1} (eight VGPRs)
+  const v4d accs[DQ_F64_RG] = {a0, a2, a4, a6};
+  double* dst_base = out + (nsplit > 1 ? (int64_t)sp * out_rows_total * ldo : 0);
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int col = v * 32 + q * 2;
+    double cv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cv[i] = (cvec && nsplit == 1 && col + i < ncols) ? cvec[col + i] : 0.0;
+#pragma unroll
+    for (int j = 0; j < DQ_F64_RG; ++j) {
+      const int r = 4 * j + g;
+      if (r < my_rows) {
+        const int64_t spos = (int64_t)row0 + 4 * quad0 + r;   // slot position -> output row
+        double* y = dst_base + (perm ? (int64_t)perm[spos] : spos) * ldo + col;
+        const double x0 = v ? accs[j].z : accs[j].x, x1 = v ? accs[j].w : accs[j].y;
+        if (col + 1 < ncols) {
+          v2d o;
+          o.x = x0 - cv[0]; o.y = x1 - cv[1];
+          *reinterpret_cast<v2d_a8*>(y) = o;
+        } else if (col < ncols) {
+          y[0] = x0 - cv[0];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   op.dq = false;
   static const bool off = getenv("SAPCA_NO_DQ") != nullptr;
-  if (off || !op.valid || op.elem != 4 || op.fmt != 1 || op.ldp != 64 || op.tile_bytes != DQ_TILE_BYTES) return false;
-  if (op.block_rows != 512 && op.block_rows != 1024) return false;
+  static const bool off64 = getenv("SAPCA_NO_DQ_F64") != nullptr;   // f64 fits on round 1's staged-entry sweep (A/B runs)
+  if (off || !op.valid || op.fmt != 1 || op.ldp != 64 || op.tile_bytes != DQ_TILE_BYTES) return false;
+  if (op.elem == 8) {
+    if (off64 || op.block_rows != 64 * DQ_F64_RG) return false;
+  } else if (op.elem != 4 || (op.block_rows != 512 && op.block_rows != 1024)) {
+    return false;
+  }
   if (op.total_entries / DQ_OFF_UNIT >= (int64_t)1 << 32) return false;
   const int64_t nchunks = (int64_t)op.nrb * op.nct;
   const size_t info_words = ((size_t)nchunks * DQ_WAVES + 64) * 2;   // (+ a 64-tile window of slack: the sweep loads whole windows)
@@ -204,6 +292,15 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
 }
 
 bool dq_usable(const TiledOp& op, int ldx) { return op.dq && (ldx == 64 || ldx == 128); }
+
+void launch_dq_f64(const TiledOp& op, const double* X, int ldx, double* out, int ldo, int ncols, const double* cvec, hipStream_t s) {
+  static LdsAttrState attr;
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_dq_f64_kernel), DQ_LDS, attr);
+  hipLaunchKernelGGL(spmm_dq_f64_kernel, dim3((unsigned)(op.nrb * op.nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm, op.nct, op.ent,
+                     reinterpret_cast<const uint16_t*>(op.steps), op.dq_info, op.cols, X, ldx, op.nsplit, op.tiles_per_split, out, op.rows, ldo, ncols,
+                     cvec, 0);
+  SAPCA_HIP(hipGetLastError());
+}
 
 template <int RG>
 static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int flags,

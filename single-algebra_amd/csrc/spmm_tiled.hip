@@ -1845,7 +1845,9 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // the bigger tile (fewer, longer tile steps, less quad padding) when the chunks are expected to leave room
   // in the smaller staging area; operators fed by the tile-major transposition keep the default split
   // (their tile count is fixed before the transposition runs)
-  if (quad && !transposed && !rows_tile_major && allow_big_tile && !dq_candidate && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
+  // (f64 operators keep the default split too: the f64 DPP-fed sweep double-buffers the 80 KiB tile)
+  const bool dq64_candidate = !f32 && quad && getenv("SAPCA_NO_DQ") == nullptr && getenv("SAPCA_NO_DQ_F64") == nullptr;
+  if (quad && !transposed && !rows_tile_major && allow_big_tile && !dq_candidate && !dq64_candidate && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
     const int tcb = Q_TILE_BYTES_BIG / (ldp * 4);
     const double est = 1.3 * (double)S.nnz / ((double)nrb * std::ceil((double)op_cols / tcb));
     if (est <= 0.78 * (q_stage_bytes(Q_TILE_BYTES_BIG) / (int)sizeof(E) - WAVE)) {
@@ -2015,6 +2017,13 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     if (!dq_ok && (block_rows > 512 || max_chunk > stage_cap)) {   // only the DPP-fed sweep reads such operators: the caller stays on the row kernel
       SAPCA_HIP(hipStreamWaitEvent(s, buf.aux_join, 0));
       return false;
+    }
+  }
+  if constexpr (!f32) {
+    if (quad) {   // the f64 DPP-fed sweep reads the same tables (an operator it cannot take stays on the staged-entry sweep)
+      op.valid = true;
+      (void)dq_build_tables(op, buf, s);
+      op.valid = false;
     }
   }
   // quads that fit the LDS image on average: staged fill (coalesced stores, pads itself); otherwise
@@ -2280,7 +2289,8 @@ void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy,
       ldo = op.ldp;
       nc = op.ldp;
     }
-    if (op.tile_bytes == Q_TILE_BYTES_BIG) launch_quad_f64<Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, s);
+    if (op.dq) launch_dq_f64(op, Xp, ldx, out, ldo, nc, cv, s);   // the DPP-fed sweep (spmm_dq.hip)
+    else if (op.tile_bytes == Q_TILE_BYTES_BIG) launch_quad_f64<Q_TILE_BYTES_BIG>(op, Xp, ldx, out, ldo, nc, cv, s);
     else launch_quad_f64<Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, s);
     if (op.nsplit > 1) {
       const int64_t total = op.rows * (int64_t)op.ldp;

@@ -54,6 +54,39 @@ B64 = os.environ.get("DQ2_B64", "0") != "0"     # one 64-bit row_newbcast move p
 FMAC = os.environ.get("DQ2_FMAC", "0") != "0"   # four v_fmac_f32 per step instead of two v_pk_fma_f32
 P64 = [[20, 22], [24, 26]]                        # B64: even-aligned pairs, lo becomes the LDS address, hi is the value
 
+F64 = False       # set per variant in main(): the f64 sweep (16-byte entries, 512-byte panel rows, four f64 columns per lane)
+ACCW = 4          # accumulator registers per row slot (8 for f64)
+CHUNK_B = 512     # bytes of one 16-step chunk of a wave's stream (1024 for f64)
+RPP = 4           # panel rows per 1 KiB LDS-DMA piece (2 for f64)
+
+
+def set_f64(on):
+    """register map and sizes of the f64 variant: entries {u32 offset, u32 pad, f64 value}, a lane holds columns 2q, 2q+1,
+    32+2q, 32+2q+1 of its row (two ds_read_b128, 256 bytes apart), four v_fma_f64 per step"""
+    global F64, ACC, ACCW, CHUNK_B, RPP, EB, ECUR, VT, VLB, A, B, VINFO, VA64, W, VCNT, VCNT2
+    F64 = on
+    if on:
+        ACC, ACCW, CHUNK_B, RPP = 80, 8, 1024, 2
+        EB = [(10, 13), (14, 17), (18, 21)]
+        ECUR = (22, 25)                 # x = v22 (offset), value in v[24:25]
+        VT, VLB = 26, 27
+        A = [[28, 29], [30, 31]]
+        B = [[32, 34], [36, 38]]       # 64-bit value pairs
+        VINFO, VA64 = (40, 41), 42
+        W = [[44, 52], [60, 68]]       # 8 registers per step
+        VCNT, VCNT2 = 76, 77
+    else:
+        ACC, ACCW, CHUNK_B, RPP = 56, 4, 512, 4
+        EB = [(10, 11), (12, 13), (14, 15)]
+        ECUR = (16, 17)
+        VT, VLB = 18, 19
+        A = [[20, 21], [22, 23]]
+        B = [24, 26]
+        VINFO, VA64 = (28, 29), 30
+        W = [[32, 36], [40, 44]]
+        VCNT, VCNT2 = 48, 49
+
+
 # scalars
 S_C = 36                      # groups the current quad still has after this one
 S_REM = 38                    # chunks left in this tile, the one about to start included
@@ -89,6 +122,16 @@ def grp_a_parts(k):
     p = k % DEPTH
     ex, ey = ECUR
     adds, movs, reads = [], [], []
+    if F64:
+        for t in range(2):
+            adds.append(f"v_add_u32_dpp v{A[p][t]}, v{ex}, v{VLB} row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+        for t in range(2):
+            w = W[p][t]
+            reads.append(f"ds_read_b128 v[{w}:{w + 3}], v{A[p][t]}")
+            reads.append(f"ds_read_b128 v[{w + 4}:{w + 7}], v{A[p][t]} offset:256")
+        for t in range(2):
+            movs.append(f"v_mov_b64_dpp v[{B[p][t]}:{B[p][t] + 1}], v[{ex + 2}:{ex + 3}] row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
+        return adds, movs, reads
     if B64:
         for t in range(2):
             adds.append(f"v_mov_b64_dpp v[{P64[p][t]}:{P64[p][t] + 1}], v[{ex}:{ey}] row_newbcast:{2 * k + t} row_mask:0xf bank_mask:0xf")
@@ -117,12 +160,16 @@ def grp_a(k, L):
 def grp_fma_parts(s, k):
     """the FMAs of group k into slot s's accumulators: (first step, second step)"""
     p = k % DEPTH
-    a = ACC + 4 * s
+    a = ACC + ACCW * s
     out = []
     for t in range(2):
         w = W[p][t]
         L = []
-        if FMAC:
+        if F64:
+            b = B[p][t]
+            for c in range(4):
+                L.append(f"v_fma_f64 v[{a + 2 * c}:{a + 2 * c + 1}], v[{w + 2 * c}:{w + 2 * c + 1}], v[{b}:{b + 1}], v[{a + 2 * c}:{a + 2 * c + 1}]")
+        elif FMAC:
             val = P64[p][t] + 1 if B64 else B[p] + t
             for c in range(4):
                 L.append(f"v_fmac_f32 v{a + c}, v{val}, v{w + c}")
@@ -191,8 +238,9 @@ def dma_piece(L):
 
 def ptr_from_off8(L, s_off8, dst, base):
     """s[dst:dst+1] = base (64-bit operand name) + 64 * s_off8   (s_off8: entry offset in units of 8 entries)"""
-    L.append(f"s_lshl_b32 s{S_CC}, s{s_off8}, {5 if ODD else 6}")   # (ODD: streams start at multiples of 4 entries, 32 bytes)
-    L.append(f"s_lshr_b32 s{S_D}, s{s_off8}, {27 if ODD else 26}")
+    sh = (5 if ODD else 6) + (1 if F64 else 0)   # (ODD: streams start at multiples of 4 entries; f64: 16-byte entries)
+    L.append(f"s_lshl_b32 s{S_CC}, s{s_off8}, {sh}")
+    L.append(f"s_lshr_b32 s{S_D}, s{s_off8}, {32 - sh}")
     L.append(f"s_mov_b64 s[{dst}:{dst + 1}], %[{base}]")
     L.append(f"s_add_u32 s{dst}, s{dst}, s{S_CC}")
     L.append(f"s_addc_u32 s{dst + 1}, s{dst + 1}, s{S_D}")
@@ -214,7 +262,7 @@ def bodies(L):
         for k in range(8):
             L.append(f"body_{s}_{k}:")
             ahead = min(DEPTH, 8 - k) - 1
-            L.append(f"s_waitcnt lgkmcnt({2 * ahead})")
+            L.append(f"s_waitcnt lgkmcnt({(4 if F64 else 2) * ahead})")
             f0, f1 = grp_fma_parts(s, k)
             if ODD:
                 L += f0
@@ -267,6 +315,11 @@ def stubs(L):
     L.append(f"s_setpc_b64 s[{S_CTL}:{S_CTL + 1}]")
 
 
+def LOAD():
+    """the chunk load: 8 bytes per lane (f32 entries) or 16"""
+    return "global_load_dwordx4" if F64 else "global_load_dwordx2"
+
+
 def chunk_routines(L, pattern):
     """ctl_r: the chunk in entry buffer r is about to run.  Its entries are complete at vmcnt(2): every chunk slot issues
     exactly one entry load, as its last vector-memory operation, so two younger loads (and whatever came with them) may
@@ -275,7 +328,10 @@ def chunk_routines(L, pattern):
         e = EB[r]
         L.append(f"ctl_{r}:")
         L.append("s_waitcnt vmcnt(2)")
-        L += [f"v_mov_b32 v{ECUR[0]}, v{e[0]}", f"v_mov_b32 v{ECUR[1]}, v{e[1]}"]
+        if F64:
+            L += [f"v_mov_b32 v{ECUR[0]}, v{e[0]}", f"v_mov_b32 v{ECUR[0] + 2}, v{e[0] + 2}", f"v_mov_b32 v{ECUR[0] + 3}, v{e[0] + 3}"]
+        else:
+            L += [f"v_mov_b32 v{ECUR[0]}, v{e[0]}", f"v_mov_b32 v{ECUR[1]}, v{e[1]}"]
         if pattern:
             # pattern mode (MaskedSparsePCA's projection, quirk Q3): every stored non-zero value counts as 1, zeros
             # (padding, and stored zeros, which the caller handles) as 0
@@ -284,8 +340,8 @@ def chunk_routines(L, pattern):
         L += [f"s_cmp_lg_u32 s{S_NP}, 0", f"s_cbranch_scc1 dma_{r}", f"dmaback_{r}:"]
         # the buffer's next load: three chunks ahead in this tile; in the last three slots the next tile's first chunks (linked)
         L += [f"s_cmp_le_u32 s{S_REM}, 3", f"s_cbranch_scc1 tail_{r}",
-              f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:1536 nt", f"issued_{r}:"]
-        L += [f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"s_add_u32 s{S_PTR}, s{S_PTR}, 0x200", f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0",
+              f"{LOAD()} v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{3 * CHUNK_B} nt", f"issued_{r}:"]
+        L += [f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"s_add_u32 s{S_PTR}, s{S_PTR}, {CHUNK_B}", f"s_addc_u32 s{S_PTR + 1}, s{S_PTR + 1}, 0",
               f"s_sub_u32 s{S_REM}, s{S_REM}, 1",
               f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[(r + 1) % 3]}:{S_CTLA[(r + 1) % 3] + 1}]"]
         for k in range(DEPTH):
@@ -302,18 +358,18 @@ def chunk_routines(L, pattern):
               f"s_cmp_lg_u32 s{S_REM}, 3", f"s_cbranch_scc1 nocnt_{r}",
               f"global_load_ushort v{VCNT2}, %[l2c], s[{S_STP}:{S_STP + 1}] offset:512",
               f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"nocnt_{r}:",
-              f"s_sub_u32 s{S_A}, 3, s{S_REM}", f"s_lshl_b32 s{S_A}, s{S_A}, 9", f"v_add_u32 v{VT}, s{S_A}, %[eoff]",
-              f"global_load_dwordx2 v[{e[0]}:{e[1]}], v{VT}, s[{S_PTRN}:{S_PTRN + 1}] nt", f"s_branch issued_{r}",
-              f"dummy_{r}:", f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] nt", f"s_branch issued_{r}"]
+              f"s_sub_u32 s{S_A}, 3, s{S_REM}", f"s_lshl_b32 s{S_A}, s{S_A}, {10 if F64 else 9}", f"v_add_u32 v{VT}, s{S_A}, %[eoff]",
+              f"{LOAD()} v[{e[0]}:{e[1]}], v{VT}, s[{S_PTRN}:{S_PTRN + 1}] nt", f"s_branch issued_{r}",
+              f"dummy_{r}:", f"{LOAD()} v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] nt", f"s_branch issued_{r}"]
 
 
 def body(pattern):
     L = []
     # accumulators <- 0
-    for i in range(4 * RG):
+    for i in range(ACCW * RG):
         L.append(f"v_mov_b32 v{ACC + i}, 0")
     L += [f"s_mov_b32 s{S_T}, 0", f"s_mov_b32 s{S_NT}, %[ntiles]", f"s_mov_b32 s{S_TABS}, %[t0]",
-          f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], 2",
+          f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], {2 if RPP == 4 else 1}",   # panel rows a piece advances by: RPP * nct
           f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1",
           f"s_mov_b32 s{S_ND}, 0", f"s_mov_b32 s{S_PRE}, 0", f"s_mov_b32 s{S_BASE}, 0", f"s_mov_b64 s[{S_STP}:{S_STP + 1}], %[stp]"]
     # code addresses: the three chunk routines and slot 0's copy of the main loop
@@ -324,7 +380,7 @@ def body(pattern):
     # lanes that hold a quad of this wave: lane < my_quads  (l2 = 2 * lane)
     L += [f"s_lshl_b32 s{S_A}, %[myq], 1", f"v_cmp_gt_u32 vcc, s{S_A}, %[l2]", f"s_mov_b64 s[{S_QM}:{S_QM + 1}], vcc"]
     L += [f"v_readfirstlane_b32 s{S_ROWBW}, %[rowb0]", f"s_mul_i32 s{S_PSTEP}, s{S_4NCT}, %[stride]",
-          f"s_mul_i32 s{S_LIM}, %[nct], 3", f"s_add_u32 s{S_LIM}, s{S_LIM}, s{S_ROWBW}", f"s_sub_u32 s{S_LIM}, %[prm1], s{S_LIM}"]
+          f"s_mul_i32 s{S_LIM}, %[nct], {RPP - 1}", f"s_add_u32 s{S_LIM}, s{S_LIM}, s{S_ROWBW}", f"s_sub_u32 s{S_LIM}, %[prm1], s{S_LIM}"]
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
     # first tile: this wave's five pieces into buffer 0, synchronously
@@ -357,7 +413,7 @@ def body(pattern):
     # a tile that was not preloaded: its first three chunks and its step counts
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 preloaded"]
     for i, e in enumerate(EB):
-        L.append(f"global_load_dwordx2 v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{512 * i} nt")
+        L.append(f"{LOAD()} v[{e[0]}:{e[1]}], %[eoff], s[{S_PTR}:{S_PTR + 1}] offset:{CHUNK_B * i} nt")
     L.append(f"global_load_ushort v{VCNT2}, %[l2c], s[{S_STP}:{S_STP + 1}]")
     L += [f"s_add_u32 s{S_ND}, s{S_ND}, 4", f"s_mov_b32 s{S_BASE}, 0", "preloaded:"]
     # this wave's pieces of the tile have landed: wait for all but what was issued after the last of them
@@ -417,6 +473,8 @@ def set_depth_regs():
 
 
 def clobbers():
+    if F64:
+        return [f"v{i}" for i in range(10, 78)] + [f"s{i}" for i in range(36, 98)] + ["memory", "scc", "m0", "vcc"]
     v = [f"v{i}" for i in range(10, 50)]
     if DEPTH == 3:
         v += [f"v{i}" for i in range(50, 54)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 8)]
@@ -444,6 +502,19 @@ def main():
                 out.write("\n")
                 print(f"wrote {name}: {len(L)} lines")
             out.write(f"#define DQ2_MAIN_CLOBBERS_{rg} " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+        # the f64 sweep: four row slots per lane group (blocks of <= 256 rows, the f64 quad format's), accumulators from v80
+        if not (B64 or FMAC or ILV or DEPTH != 2):
+            RG = 4
+            set_f64(True)
+            _uid[0] = 0
+            L = uniq_labels(body(False))
+            out.write("#define DQ2_F64_ACC_BASE 80\n#define DQ2_MAIN_ASM_F64 \\\n")
+            for ln in L:
+                out.write(f'  "{ln}\\n" \\\n')
+            out.write("\n")
+            out.write("#define DQ2_MAIN_CLOBBERS_F64 " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+            print(f"wrote DQ2_MAIN_ASM_F64: {len(L)} lines")
+            set_f64(False)
 
 
 if __name__ == "__main__":
