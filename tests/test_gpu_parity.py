@@ -850,6 +850,45 @@ def test_g6_lanczos_masked(golden):
     assert est.components_().shape == (k, int(g["mask"].sum())) and est.mean_().shape == (n,)
 
 
+@pytest.mark.parametrize("dtype,masked", [(np.float64, True), (np.float64, False), (np.float32, True)])
+def test_lanczos_without_a_transposed_operator(monkeypatch, dtype, masked):
+    """Lanczos fits whose transposed side fits LDS build no A^T: the second product of a step scatters A's rows into
+    per-workgroup FIXED-POINT copies of the output (scatter.hip), the column statistics come from the same kind of pass.
+    (1) bit-for-bit reproducible (integer sums: no order dependence); (2) the same fit as the transposed route
+    (SAPCA_LANCZOS_TRANSPOSE=1: radix sort + gather along A^T's rows) to rounding; (3) mean_ / total variance against the
+    oracle; (4) the exact SVD of the dense operator."""
+    m, n, k = 7000, 1100, 6
+    t = torch.float64 if dtype == np.float64 else torch.float32
+    dev = synth.gapped_csr(m, n, 0.05, k, seed=17, centred=False, dtype=t, device="cuda")
+    ptr, idx, val = csr_np(dev)
+    mask = synth.bernoulli_mask(n, 0.6, 5).numpy() if masked else None
+    def build():
+        b = sapca.MaskedSparsePCABuilder.new().mask(mask) if masked else sapca.SparsePCABuilder.new()
+        return b.n_components(k).svd_method(SVDMethod.Lanczos()).build()
+    x = sapca.DeviceCsr(*dev, (m, n))
+    a, b = build(), build()
+    ta, tb = a.fit_transform(x), b.fit_transform(x)
+    assert np.array_equal(a.components_(np.float64), b.components_(np.float64)) and torch.equal(ta, tb)      # (1)
+    assert np.array_equal(a.mean_(np.float64), b.mean_(np.float64))
+    monkeypatch.setenv("SAPCA_LANCZOS_TRANSPOSE", "1")
+    c = build()
+    tc = c.fit_transform(x)
+    f32 = dtype == np.float32
+    np.testing.assert_allclose(a.singular_values_(np.float64), c.singular_values_(np.float64), rtol=1e-6 if f32 else 1e-10)   # (2)
+    assert O.subspace_angle(a.components_(np.float64), c.components_(np.float64)) < (1e-5 if f32 else 1e-8)
+    np.testing.assert_allclose(a.mean_(np.float64), c.mean_(np.float64), rtol=1e-6 if f32 else 1e-13, atol=1e-12)
+    np.testing.assert_allclose(ta.cpu().numpy(), tc.cpu().numpy(), atol=(1e-3 if f32 else 1e-8) * float(tc.abs().max()))
+    v64 = val.astype(np.float64)                                                                             # (3)
+    want_mean = np.bincount(idx, weights=v64, minlength=n) / m
+    np.testing.assert_allclose(a.mean_(np.float64), want_mean, rtol=2e-6 if f32 else 1e-13, atol=1e-12)
+    D = mat(ptr, idx, v64, m, n).toarray()                                                                   # (4)
+    if masked:
+        D = D[:, mask]
+    _, sv, vt = np.linalg.svd(D, full_matrices=False)
+    np.testing.assert_allclose(a.singular_values_(np.float64), sv[:k], rtol=1e-5)
+    assert O.subspace_angle(a.components_(np.float64), vt[:k]) < 1e-4
+
+
 def test_lanczos_wide_matrix_uses_the_small_side():
     """m < n: las2 iterates on A A^T and recovers the right vectors."""
     m, n, k = 300, 2000, 5
