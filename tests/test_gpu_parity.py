@@ -714,6 +714,37 @@ def test_production_dispatch_against_the_oracle():
     np.testing.assert_allclose(t, want, atol=2e-3 * np.abs(want).max())
 
 
+def test_c2_at_full_size_against_the_oracle():
+    """BASELINE configs[1] at its full size (200k x 20k f32, 1.2e8 stored entries, k=50, p=10, q=4, QR) against the C
+    restatement of the reference algorithm (f64, all host cores, about a minute) with the same injected Omega: the
+    north-star tolerances, not a property."""
+    import orc
+    m, n, density, k, p, q = 200_000, 20_000, 0.03, 50, 10, 4
+    dev = synth.gapped_csr(m, n, density, k, seed=42, dtype=torch.float32, device="cuda")
+    om = synth.gaussian_panel(n, k + p, 42).numpy().astype(np.float32)
+    pca = _builder(k, p, q).collect_timings(True).build().set_omega(om)
+    t = pca.fit_transform(sapca.DeviceCsr(*dev, (m, n)))
+    assert int(pca.timings().sweep_kernel) == 2
+    ptr, idx, val = csr_np(dev)
+    val = val.astype(np.float64)
+    rc, comps, sing, ev, mean, tv = orc.randomized_fit(ptr, idx, val, m, n, k, p, q, "QR", True, om.astype(np.float64))
+    assert rc == 0
+    np.testing.assert_allclose(pca.singular_values_(np.float64), sing[:k], rtol=1e-4)
+    assert O.subspace_angle(pca.components_(np.float64), comps[:k].astype(np.float64)) < 1e-4
+    ratio = (sing[:k].astype(np.float64) ** 2) / (sing[:k].astype(np.float64) ** 2).sum()
+    np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), ratio, atol=1e-6)
+    np.testing.assert_allclose(pca.mean_(np.float64), mean, rtol=1e-5, atol=1e-7)
+    rows = np.arange(0, m, 997)                                  # the projection on a sample of rows (the closed form of Q2)
+    sub_ptr = np.zeros(len(rows) + 1, np.int64)
+    sub_ptr[1:] = np.cumsum(ptr[rows + 1] - ptr[rows])
+    take = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in rows])
+    cnt = np.bincount(idx, minlength=n).astype(np.float64)      # Q2 weights every feature by its stored-entry count over the WHOLE matrix
+    X = sp.csr_matrix((val[take], idx[take], sub_ptr), shape=(len(rows), n))
+    W = (comps[:k].astype(np.float64) * cnt[None, :]).T
+    want = X @ W - (mean.astype(np.float64) @ W)[None, :]
+    np.testing.assert_allclose(t[torch.as_tensor(rows, device=t.device)].cpu().numpy(), want, atol=2e-3 * np.abs(want).max())
+
+
 def test_two_column_passes_at_production_size_against_the_oracle():
     """l = 110 (k = 100, p = 10: wider than the 64-column tile, so every sweep runs two column passes over the same
     format) through the AUTO dispatch at 1.8e7 stored entries, against the C restatement with the same injected Omega:
