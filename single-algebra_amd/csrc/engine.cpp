@@ -217,6 +217,17 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   const bool try_masked_direct = sizeof(T) == 4 && at_tile_major && masked_aside && n_used <= 65536 && getenv("SAPCA_AT_SORT") == nullptr;
   bool compaction_done = false;
   bool side_stats = false;   // the masked-out columns' sums (and the host copy of all statistics) finish on stream3, behind the fit
+  // SAPCA_MASK_SUMS_SCATTER=1: single-rank masked fits take those sums straight from A on the third stream (scatter.hip:
+  // fixed-point sums in LDS) instead of sorting the (column, value) pairs the compaction writes out for it.  Measured slower
+  // on randomized fits (C3's matrix in f32: 14.0 against 12.9 ms): the scatter kernels take a CU's whole LDS, so the sweeps
+  // cannot share the chip with them the way they do with the sort's light kernels.  Not the default.
+  const bool scatter_sums = masked && !from_upload && !lz_scatter && !h.comm.active() && getenv("SAPCA_MASK_STATS_INLINE") == nullptr &&
+                            getenv("SAPCA_MASK_SUMS_SCATTER") != nullptr;
+  auto scatter_sums_on_stream3 = [&](double* d_drop) {   // sum | sumsq of EVERY column of A (the kept ones are overwritten later)
+    unsigned long long* sc = h.lz_scalars.as<unsigned long long>(4);
+    k::absmax(A.val, nnz, sc, h.stream3);
+    k::colstats_scatter(A, sc, d_drop, d_drop + n, (double*)nullptr, h.drop_tmp, h.stream3);
+  };
   int32_t* drop_col = nullptr;
   T* drop_val = nullptr;
   if (masked_aside && getenv("SAPCA_MASK_TRANSPOSE_FIRST") == nullptr) {
@@ -224,8 +235,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
     int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    drop_col = (from_upload || lz_scatter) ? nullptr : h.drop_col.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
-    drop_val = (from_upload || lz_scatter) ? nullptr : h.drop_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
+    drop_col = (from_upload || lz_scatter || scatter_sums) ? nullptr : h.drop_col.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+    drop_val = (from_upload || lz_scatter || scatter_sums) ? nullptr : h.drop_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
     k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val);
     h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
     compaction_done = true;
@@ -257,9 +268,12 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         double* d_drop = h.drop_stats.as<double>((size_t)2 * n);
         SAPCA_HIP(hipEventRecord(h.ev_drop, s));
         SAPCA_HIP(hipStreamWaitEvent(h.stream3, h.ev_drop, 0));
-        k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
-                          h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
-                          d_drop, d_drop + n, h.drop_tmp, h.stream3);
+        if (scatter_sums)
+          scatter_sums_on_stream3(d_drop);
+        else
+          k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                            h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                            d_drop, d_drop + n, h.drop_tmp, h.stream3);
       }
     }
   }
@@ -558,10 +572,14 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     double* d_drop = h.drop_stats.as<double>((size_t)2 * n);
     SAPCA_HIP(hipEventRecord(h.ev_kept, s));
     SAPCA_HIP(hipStreamWaitEvent(h.stream3, h.ev_kept, 0));
-    if (h.opt.method == SAPCA_RANDOM)
-      k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
-                        h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
-                        d_drop, d_drop + n, h.drop_tmp, h.stream3);
+    if (h.opt.method == SAPCA_RANDOM) {
+      if (scatter_sums)
+        scatter_sums_on_stream3(d_drop);
+      else
+        k::sums_by_column(drop_col, drop_val, nnz - nnz_used, n, h.at_ptr.as<int64_t>((size_t)n + 1),
+                          h.at_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1)), h.at_val.as<T>((size_t)std::max<int64_t>(nnz, 1)),
+                          d_drop, d_drop + n, h.drop_tmp, h.stream3);
+    }
     k::copy_selected(d_stats, d_stats + n, d_sel, n_used, d_drop, d_drop + n, h.stream3);
     SAPCA_HIP(hipMemcpyAsync(sums, d_drop, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, h.stream3));
     SAPCA_HIP(hipEventRecord(h.ev_stats, h.stream3));

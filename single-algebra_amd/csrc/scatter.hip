@@ -129,13 +129,33 @@ vecmax_kernel(const double* __restrict__ y, int64_t len, unsigned long long* __r
   if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(out_bits, b);
 }
 
-// Column statistics of columns [c0, c0 + nc): per workgroup fixed-point sums of a and a^2 and entry counts in LDS.
-// A row's entries inside the range are a contiguous run (column indices ascend): lanes walk the row and skip what lies outside.
+// bounds[r][p] = first entry of row r (relative to the row's start) with a column index >= p * nc_pass, p = 1 .. passes - 1:
+// the statistics passes below then read only the entries of their own column range (column indices ascend along a row)
+__global__ void __launch_bounds__(256)
+colrange_bounds_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t rows, int nc_pass, int passes,
+                       uint32_t* __restrict__ bounds) {
+  const int64_t total = rows * (int64_t)(passes - 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / (passes - 1);
+    const int p = (int)(i % (passes - 1)) + 1;
+    const int64_t e0 = ptr[r];
+    int64_t lo = e0, hi = ptr[r + 1];
+    const int target = p * nc_pass;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (idx[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    bounds[i] = (uint32_t)(lo - e0);
+  }
+}
+
+// Column statistics of columns [c0, c0 + nc) (pass p of `passes`): per workgroup fixed-point sums of a and a^2 and entry
+// counts in LDS.  A row's entries inside the range are the run [bounds[r][p], bounds[r][p + 1]) of the row.
 template <typename T>
 __global__ void __launch_bounds__(SC_THREADS)
 colstats_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const T* __restrict__ val, int64_t rows, int c0,
-                        int nc, const unsigned long long* __restrict__ amax_bits, long long* __restrict__ part_sum,
-                        long long* __restrict__ part_sq, unsigned int* __restrict__ part_cnt) {
+                        int nc, int p, int passes, const uint32_t* __restrict__ bounds, const unsigned long long* __restrict__ amax_bits,
+                        long long* __restrict__ part_sum, long long* __restrict__ part_sq, unsigned int* __restrict__ part_cnt) {
   extern __shared__ long long cs_lds[];
   long long* ss = cs_lds;
   long long* sq = cs_lds + nc;
@@ -148,15 +168,15 @@ colstats_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int64_t nwaves = (int64_t)gridDim.x * blockDim.x / WAVE;
   for (int64_t r = wave; r < rows; r += nwaves) {
-    const int64_t e1 = ptr[r + 1];
-    for (int64_t e = ptr[r] + lane; e < e1; e += WAVE) {
+    const int64_t e0 = ptr[r];
+    const int64_t lo = e0 + (p > 0 ? (int64_t)bounds[r * (passes - 1) + (p - 1)] : 0);
+    const int64_t hi = p + 1 < passes ? e0 + (int64_t)bounds[r * (passes - 1) + p] : ptr[r + 1];
+    for (int64_t e = lo + lane; e < hi; e += WAVE) {
       const int c = idx[e] - c0;
-      if (c >= 0 && c < nc) {
-        const double v = (double)val[e];
-        atomicAdd(reinterpret_cast<unsigned long long*>(ss + c), (unsigned long long)__double2ll_rn(v * s1));
-        atomicAdd(reinterpret_cast<unsigned long long*>(sq + c), (unsigned long long)__double2ll_rn(v * v * s2));
-        atomicAdd(cn + c, 1u);
-      }
+      const double v = (double)val[e];
+      atomicAdd(reinterpret_cast<unsigned long long*>(ss + c), (unsigned long long)__double2ll_rn(v * s1));
+      atomicAdd(reinterpret_cast<unsigned long long*>(sq + c), (unsigned long long)__double2ll_rn(v * v * s2));
+      atomicAdd(cn + c, 1u);
     }
   }
   __syncthreads();
@@ -199,8 +219,9 @@ colstats_reduce_kernel(const long long* __restrict__ part_sum, const long long* 
     unsigned long long tn = 0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) { ta += sa[g][lane]; tb += sb[g][lane]; tn += sn[g][lane]; }
-    sum[c0 + c] = (double)ta * i1;
-    sumsq[c0 + c] = (double)tb * i2;
+    const bool bad = !(amax <= 1.7976931348623157e308);   // inf / nan among the values: no fixed-point scale exists
+    sum[c0 + c] = bad ? amax : (double)ta * i1;
+    sumsq[c0 + c] = bad ? amax : (double)tb * i2;
     if (cnt) cnt[c0 + c] = (double)tn;
   }
 }
@@ -255,17 +276,23 @@ void colstats_scatter(const CsrView<T>& A, const unsigned long long* amax_bits, 
   const int max_nc = kScatterLds / per_col;
   const int passes = (int)((A.cols + max_nc - 1) / max_nc);
   const int nc_pass = (int)((A.cols + passes - 1) / passes);
-  char* base = static_cast<char*>(scratch.ensure((size_t)kParts * nc_pass * per_col));
+  const size_t part_bytes = (size_t)kParts * nc_pass * per_col;
+  const size_t bounds_bytes = passes > 1 ? (size_t)A.rows * (passes - 1) * sizeof(uint32_t) : 0;
+  char* base = static_cast<char*>(scratch.ensure(part_bytes + bounds_bytes + 64));
   long long* ps = reinterpret_cast<long long*>(base);
   long long* pq = ps + (size_t)kParts * nc_pass;
   unsigned int* pc = reinterpret_cast<unsigned int*>(pq + (size_t)kParts * nc_pass);
+  uint32_t* bounds = reinterpret_cast<uint32_t*>(base + ((part_bytes + 15) & ~(size_t)15));
+  if (passes > 1)
+    hipLaunchKernelGGL(colrange_bounds_kernel, dim3((unsigned)std::min<int64_t>((A.rows * (passes - 1) + 255) / 256, 8192)), dim3(256), 0, s, A.ptr,
+                       A.idx, A.rows, nc_pass, passes, bounds);
   static LdsAttrState attr;
   ensure_dynamic_lds(reinterpret_cast<const void*>(&colstats_scatter_kernel<T>), kScatterLds, attr);
   for (int p = 0; p < passes; ++p) {
     const int c0 = p * nc_pass, nc = (int)std::min<int64_t>(nc_pass, A.cols - c0);
     if (nc <= 0) break;
     hipLaunchKernelGGL((colstats_scatter_kernel<T>), dim3(kParts), dim3(SC_THREADS), (size_t)nc * per_col, s, A.ptr, A.idx, A.val, A.rows, c0, nc,
-                       amax_bits, ps, pq, pc);
+                       p, passes, bounds, amax_bits, ps, pq, pc);
     hipLaunchKernelGGL(colstats_reduce_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(1024), 0, s, ps, pq, pc, kParts, A.rows, c0, nc, amax_bits, sum,
                        sumsq, cnt);
   }
