@@ -183,15 +183,11 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   bool lz_scatter = h.opt.method == SAPCA_LANCZOS && n_used > 0 && n_used <= m && m >= 4096 && nnz > 0 && k::scatter_fits(n_used) &&
                     (!masked || !serial_early) && getenv("SAPCA_LANCZOS_TRANSPOSE") == nullptr;
   bool lz_side = false;   // its statistics run on the third stream
-  if (lz_scatter) {
-    unsigned long long* sc = h.lz_scalars.as<unsigned long long>(4);   // max |a| ; max |y| of even / odd steps
-    k::absmax(A.val, nnz, sc, s);
-    unsigned long long bits = 0;
-    SAPCA_HIP(hipMemcpyAsync(&bits, sc, sizeof(bits), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipStreamSynchronize(s));
-    double amax;
-    std::memcpy(&amax, &bits, sizeof(amax));
-    lz_scatter = std::isfinite(amax);   // (inf / nan among the values: the floating-point route carries them through)
+  if (lz_scatter && !masked) {
+    // max |a| for the fixed-point scales (masked fits: the compaction gathers it on its way through the values).  Values that
+    // are not finite turn the scale, and with it every product and sum, into nan: the fit then fails to converge, as it does
+    // on the floating-point route.
+    k::absmax(A.val, nnz, h.lz_scalars.as<unsigned long long>(4), s);
   }
   h.lz_scatter = lz_scatter;
 
@@ -237,7 +233,8 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     T* ca_val = h.ca_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
     drop_col = (from_upload || lz_scatter || scatter_sums) ? nullptr : h.drop_col.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     drop_val = (from_upload || lz_scatter || scatter_sums) ? nullptr : h.drop_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
-    k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val);
+    k::compact_columns(A, d_o2m, ca_ptr, ca_idx, ca_val, &nnz_used, h.scratch, s, drop_col, drop_val,
+                       lz_scatter ? h.lz_scalars.as<unsigned long long>(4) : nullptr);
     h.a_used = {m, n_used, nnz_used, ca_ptr, ca_idx, ca_val};
     compaction_done = true;
     if (!from_upload && !lz_scatter) {

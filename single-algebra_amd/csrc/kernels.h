@@ -24,7 +24,9 @@ void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s);
 // Mask compaction of A: keep entries with o2m[col] >= 0, renumbered.  Two passes around a scan.
 template <typename T>
 void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
-                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col = nullptr, T* drop_val = nullptr);
+                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col = nullptr, T* drop_val = nullptr,
+                     unsigned long long* amax_bits = nullptr);
+// (amax_bits: receives the bit pattern of max |value| over ALL stored entries of A as a double, a quiet nan's if one is not finite)
 // (drop_col / drop_val, A.nnz each, receive the entries that were NOT kept as (original column, value) pairs, row after row)
 // sum[c], sumsq[c] (c < n) over (column, value) pairs through a stable sort by column; seg (n + 1), keys_out, vals_out: work arrays
 template <typename T>

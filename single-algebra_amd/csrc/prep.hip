@@ -265,8 +265,10 @@ template <typename T>
 __global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                   const T* __restrict__ val, int64_t rows, const int32_t* __restrict__ o2m, int64_t n, int words,
                                   const int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_idx,
-                                  T* __restrict__ new_val, int32_t* __restrict__ drop_col, T* __restrict__ drop_val) {
+                                  T* __restrict__ new_val, int32_t* __restrict__ drop_col, T* __restrict__ drop_val,
+                                  unsigned long long* __restrict__ amax_bits) {
   extern __shared__ uint32_t cmap_lds[];
+  double vmax = 0.0;   // max |value| over EVERY stored entry the thread sees (kept or not), nan once one is not finite
   uint32_t* bits = cmap_lds;
   uint32_t* before = cmap_lds + words;
   if (words > 0) load_column_map(o2m, n, words, bits, before);
@@ -285,6 +287,13 @@ __global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
         const int64_t e = base + u * WAVE + lane;
         col[u] = e < e1 ? idx[e] : -1;
         v[u] = e < e1 ? val[e] : (T)0;
+      }
+      if (amax_bits) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double a = fabs((double)v[u]);
+          vmax = (a <= 1.7976931348623157e308 && vmax == vmax) ? fmax(vmax, a) : __longlong_as_double(0x7ff8000000000000ll);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -316,6 +325,12 @@ __global__ void write_kept_kernel(const int64_t* __restrict__ ptr, const int32_t
         }
       }
     }
+  }
+  if (amax_bits) {   // bit patterns of non-negative doubles order like unsigned integers; the quiet nan's lies above all of them
+    unsigned long long b = (unsigned long long)__double_as_longlong(vmax);
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) b = max(b, (unsigned long long)__shfl_xor((long long)b, off));
+    if (lane == 0) atomicMax(amax_bits, b);
   }
 }
 
@@ -589,7 +604,8 @@ void row_sums(const CsrView<T>& At, double* sum, double* sumsq, hipStream_t s) {
 
 template <typename T>
 void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, int32_t* new_idx, T* new_val,
-                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col, T* drop_val) {
+                     int64_t* new_nnz_host, DevBuf& scratch, hipStream_t s, int32_t* drop_col, T* drop_val, unsigned long long* amax_bits) {
+  if (amax_bits) SAPCA_HIP(hipMemsetAsync(amax_bits, 0, sizeof(unsigned long long), s));
   // (every workgroup rebuilds the column map in LDS from o2m: few, long-lived workgroups)
   const int g = grid_for(A.rows * WAVE, 256, 2048);
   int words = (int)std::min<int64_t>((A.cols + 31) / 32, 1 << 30);
@@ -598,7 +614,7 @@ void compact_columns(const CsrView<T>& A, const int32_t* o2m, int64_t* new_ptr, 
   hipLaunchKernelGGL((count_kept_kernel<T>), dim3(g), dim3(256), lds, s, A.ptr, A.idx, A.rows, o2m, A.cols, words, new_ptr);
   exclusive_scan_i64(new_ptr, A.rows + 1, scratch, 0, s);
   hipLaunchKernelGGL((write_kept_kernel<T>), dim3(g), dim3(256), lds, s, A.ptr, A.idx, A.val, A.rows, o2m, A.cols, words, new_ptr,
-                     new_idx, new_val, drop_col, drop_val);
+                     new_idx, new_val, drop_col, drop_val, amax_bits);
   SAPCA_HIP(hipGetLastError());
   SAPCA_HIP(hipMemcpyAsync(new_nnz_host, new_ptr + A.rows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   SAPCA_HIP(hipStreamSynchronize(s));
@@ -728,7 +744,7 @@ void build_tile_index(const CsrView<T>& A, int tile_cols, int n_tiles, int32_t* 
                                  const uint64_t**);                                                                 \
   template void row_sums<T>(const CsrView<T>&, double*, double*, hipStream_t);                                      \
   template void compact_columns<T>(const CsrView<T>&, const int32_t*, int64_t*, int32_t*, T*, int64_t*, DevBuf&,    \
-                                   hipStream_t, int32_t*, T*);                                                      \
+                                   hipStream_t, int32_t*, T*, unsigned long long*);                                 \
   template void sums_by_column<T>(const int32_t*, const T*, int64_t, int64_t, int64_t*, int32_t*, T*, double*, double*, DevBuf&,   \
                                   hipStream_t);                                                                     \
   template void select_rows<T>(const CsrView<T>&, const int32_t*, int64_t, int64_t*, int32_t*, T*, int64_t*,        \

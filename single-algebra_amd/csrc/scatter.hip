@@ -27,6 +27,7 @@ constexpr int SC_THREADS = 1024;
 
 // 2^e with  total * 2^e < 2^61  (total: a bound of the magnitude of any accumulated sum); 0 for an empty / zero operator
 __device__ inline double fixed_scale(double total) {
+  if (!(total <= 1.7976931348623157e308)) return total - total;   // inf / nan among the values: nan, and every sum with it
   if (!(total > 0.0)) return 0.0;
   int e;
   (void)frexp(total, &e);   // total < 2^e
@@ -97,7 +98,7 @@ spmvt_reduce_kernel(const long long* __restrict__ part, int nparts, int64_t rows
                     const unsigned long long* __restrict__ ymax_bits, unsigned long long* __restrict__ clear_bits, double* __restrict__ z) {
   __shared__ long long acc[16][64];
   const double scale = fixed_scale((double)rows * bits_to_double(*amax_bits) * bits_to_double(*ymax_bits));
-  const double inv = scale > 0.0 ? 1.0 / scale : 0.0;   // (a power of two: exact)
+  const double inv = scale == 0.0 ? 0.0 : 1.0 / scale;   // (a power of two: exact; nan stays nan)
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
   const int per = (nparts + 15) / 16;
@@ -195,7 +196,7 @@ colstats_reduce_kernel(const long long* __restrict__ part_sum, const long long* 
   __shared__ unsigned long long sn[16][64];
   const double amax = bits_to_double(*amax_bits);
   const double s1 = fixed_scale((double)rows * amax), s2 = fixed_scale((double)rows * amax * amax);
-  const double i1 = s1 > 0.0 ? 1.0 / s1 : 0.0, i2 = s2 > 0.0 ? 1.0 / s2 : 0.0;
+  const double i1 = s1 == 0.0 ? 0.0 : 1.0 / s1, i2 = s2 == 0.0 ? 0.0 : 1.0 / s2;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int per = (nparts + 15) / 16;
