@@ -314,6 +314,10 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   bool at_direct = false;
   if constexpr (sizeof(T) == 4) {
     if (try_direct) {
+      if (getenv("SAPCA_PREPARE_ASIDE_FIRST") && aside.joinable()) {   // timing runs: A's format alone on the chip, then A^T's
+        aside.join();
+        SAPCA_HIP(hipStreamSynchronize(h.stream2));
+      }
       Scope sc(h, C_PREPARE);
       int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
       double* d_stats = h.stats.as<double>((size_t)3 * n + 1);

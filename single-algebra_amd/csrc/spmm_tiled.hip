@@ -607,7 +607,8 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   constexpr int EW = (int)sizeof(E) / 4;   // entry size in LDS words
   extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
   E* stage = reinterpret_cast<E*>(qf_lds);         // [cap]
-  uint32_t* lofs = qf_lds + EW * cap;               // [nct + 1] start of every tile's segment in the image
+  int64_t* gofs = reinterpret_cast<int64_t*>(qf_lds + EW * cap);   // [nct] where the quad's segment of tile t goes
+  uint32_t* lofs = qf_lds + EW * cap + 2 * nct;     // [nct + 1] start of every tile's segment in the image
   uint32_t* cnt_all = lofs + nct + 1;              // [4][nct] entries of row g seen so far in tile t
   const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
@@ -628,6 +629,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
       mx = max(mx, sg[t + 1] - sg[t]);
     }
     lofs[t + 1] = (uint32_t)q_steps(mx) * 4u;
+    gofs[t] = coff[t] + (int64_t)qoff[t];   // (fetched here, beside the segment bounds: the write-out below waits on LDS only)
     for (int g = 0; g < 4; ++g) cnt_all[g * nct + t] = 0;
   }
   if (threadIdx.x == 0) lofs[0] = 0;
@@ -659,13 +661,13 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
       const int32_t* sg = seg + rowof[wave] * (nct + 1);
       for (int t = lane; t < nct; t += WAVE) {
         const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
-        E* dst = ent + coff[t] + qoff[t];
+        E* dst = ent + gofs[t];
         for (uint32_t k = (uint32_t)(sg[t + 1] - sg[t]); k < steps; ++k) dst[k * 4u + wave] = E();
       }
     } else {
       for (int t = lane; t < nct; t += WAVE) {   // rows past the end of the block: all padding
         const uint32_t steps = (lofs[t + 1] - lofs[t]) / 4u;
-        E* dst = ent + coff[t] + qoff[t];
+        E* dst = ent + gofs[t];
         for (uint32_t k = 0; k < steps; ++k) dst[k * 4u + wave] = E();
       }
     }
@@ -697,7 +699,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
           x.val = v[u];
           const uint32_t k = atomicAdd(&cnt[t], 1u);
           if (staged) stage[lofs[t] + k * 4u + (uint32_t)wave] = x;
-          else ent[coff[t] + qoff[t] + k * 4u + (uint32_t)wave] = x;
+          else ent[gofs[t] + k * 4u + (uint32_t)wave] = x;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -707,7 +709,7 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
   __syncthreads();
   for (int t = wave; t < nct; t += 4) {
     const uint32_t lo = lofs[t], n = lofs[t + 1] - lo;
-    E* dst = ent + coff[t] + qoff[t];
+    E* dst = ent + gofs[t];
     for (uint32_t j = lane; j < n; j += WAVE) dst[j] = stage[lo + j];
   }
 }
@@ -1482,9 +1484,14 @@ constexpr int ATD_MASK_WORDS = 10;        // 320 rows of a tile
 constexpr int ATD_HIST_THREADS = 512;   // (a tile per workgroup; eight waves: three or four tiles per CU at once, no second round at C2)
 constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave one workgroup per CU: sixteen waves then (C5: 100 KB)
 
+// With `bnd` (the gather fill below, natural row order of A^T): A^T's row blocks are the contiguous column ranges
+// [n b / nrb, n (b + 1) / nrb), and bnd[b][t * tc + i] becomes the position in A's arrays of the first entry of row
+// t + i * nct whose column lies in block b or behind (b = 0..nrb; the row's end for the blocks it does not reach).  A row is
+// sorted by column, so these are the places where the block of the column changes: found in the registers that hold the
+// row's indices for the histogram anyway.
 __global__ void __launch_bounds__(ATD_HIST_THREADS_WIDE)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
-                uint16_t* __restrict__ cnt16) {
+                uint16_t* __restrict__ cnt16, int64_t n, int nrb, int64_t* __restrict__ bnd) {
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
   const int t = blockIdx.x;
   const int nw = (int)(n2 / 2);
@@ -1492,6 +1499,8 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
   for (int i = threadIdx.x; i < nw; i += nthreads) atd_h32[i] = 0u;
   __syncthreads();
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const float inv_n = 1.0f / (float)n;
+  const int64_t bstride = (int64_t)nct * tc;
   // (the next row's offsets are fetched while this row's indices are in flight: a row is one batch at C5's 500 entries)
   int64_t r = (int64_t)t + (int64_t)wave * nct;
   int64_t e0 = (wave < tc && r < m) ? ptr[r] : 0, e1 = (wave < tc && r < m) ? ptr[r + 1] : 0;
@@ -1500,14 +1509,38 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
     const int64_t rn = r + (int64_t)nwaves * nct;
     const bool more = i + nwaves < tc && rn < m;
     const int64_t n0 = more ? ptr[rn] : 0, n1 = more ? ptr[rn + 1] : 0;
-    for (int64_t eb = e0 + lane; eb < e1; eb += 8 * WAVE) {   // eight loads in flight per lane
+    int lastb = -1;   // block of the last entry seen in this row (wave-uniform)
+    for (int64_t base = e0; base < e1; base += 8 * WAVE) {   // eight loads in flight per lane (a wave-uniform trip count: the
+      const int64_t eb = base + lane;                         //  boundary search below talks across lanes)
       int c[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) c[u] = eb + u * WAVE < e1 ? idx[eb + u * WAVE] : -1;
+      if (bnd) {   // (ahead of the LDS atomics: nothing here waits on the LDS queue)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool valid = c[u] >= 0;   // (valid lanes are a prefix of the wave)
+          const unsigned long long valids = __ballot(valid);
+          if (valids == 0ull) break;
+          // block of column c: the b with n b / nrb <= c < n (b + 1) / nrb (integer quotients), i.e. (c nrb + nrb - 1) / n;
+          // the numerator stays below 2^24 + 2^8 (c < 65536, nrb <= 256): a float quotient is off by one at most
+          const uint32_t x = __umul24((uint32_t)max(c[u], 0), (uint32_t)nrb) + (uint32_t)nrb - 1u;
+          uint32_t q = (uint32_t)((float)x * inv_n);
+          const int32_t rem = (int32_t)(x - __umul24(q, (uint32_t)n));
+          q = rem < 0 ? q - 1u : (rem >= (int32_t)n ? q + 1u : q);
+          const int b = (int)q;
+          const int up = __builtin_amdgcn_update_dpp(0, b, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane l reads lane l - 1
+          const int prev = lane == 0 ? lastb : up;
+          if (valid && b != prev)
+            for (int j = prev + 1; j <= b; ++j) bnd[(int64_t)j * bstride + (int64_t)t * tc + i] = eb + u * WAVE;
+          lastb = __builtin_amdgcn_readlane(b, __builtin_popcountll(valids) - 1);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (c[u] >= 0) atomicAdd(&atd_h32[c[u] >> 1], 1u << (16 * (c[u] & 1)));   // (at most 320 rows per tile: no carry into the neighbour)
     }
+    if (bnd)
+      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd[(int64_t)j * bstride + (int64_t)t * tc + i] = e1;
     r = rn;
     e0 = n0;
     e1 = n1;
@@ -1621,17 +1654,41 @@ atd_scatter_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ 
 // of this tile from the assembled segments
 constexpr int ATD_STAGE_ENT = 4096;   // entries of the LDS image (a quad holds at most 4 x 320)
 
+// GATHER (natural row order of A^T: a block is a contiguous column range): the chunk's entries come straight from A -- in
+// every row of the tile the columns of the block are one contiguous run, whose ends atd_hist_kernel left in `bnd` -- and
+// there are no buckets and no scatter pass.  A thread takes every 1024th entry of the concatenated runs.
+template <bool GATHER>
 __global__ void __launch_bounds__(ATD_THREADS, 8)   // 64 VGPRs: two workgroups per CU
 atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bucket_off, const int32_t* __restrict__ blk_row0,
                 const uint32_t* __restrict__ perm, int nct, int ldp_bytes, const int64_t* __restrict__ chunk_off,
                 const uint32_t* __restrict__ quad_off, const uint16_t* __restrict__ steps, Ent* __restrict__ ent,
-                double* __restrict__ psum, double* __restrict__ psq, int64_t n) {
-  __shared__ uint32_t mask[QBLOCK_ROWS * ATD_MASK_WORDS];
-  __shared__ __attribute__((aligned(16))) Ent stage[ATD_STAGE_ENT];
+                double* __restrict__ psum, double* __restrict__ psq, int64_t n,
+                const int32_t* __restrict__ a_idx, const float* __restrict__ a_val, const int64_t* __restrict__ bnd, int tc, int nrb_all) {
+  // one pool: the rows' bit masks (40 KiB) and the image the chunk is assembled in (32 KiB); once the ranks are known the
+  // masks are dead and the image takes the whole pool (chunks whose entries the threads hold in registers)
+  constexpr int MASK_WORDS_ALL = QBLOCK_ROWS * ATD_MASK_WORDS;
+  __shared__ __attribute__((aligned(16))) uint32_t pool[MASK_WORDS_ALL + 2 * ATD_STAGE_ENT];
+  uint32_t* mask = pool;
+  Ent* stage = reinterpret_cast<Ent*>(pool + MASK_WORDS_ALL);
   __shared__ uint32_t qoff_s[Q_BLOCK_QUADS + 1];
   __shared__ uint32_t wtot[Q_BLOCK_QUADS / WAVE];
-  const int64_t chunk = blockIdx.x;
-  const int rb = (int)(chunk / nct), t = (int)(chunk % nct);
+  __shared__ uint16_t len_s[QBLOCK_ROWS];
+  __shared__ int64_t run_lo[GATHER ? 32 * ATD_MASK_WORDS : 1];        // first entry of every tile row's run
+  __shared__ uint32_t run_pre[GATHER ? 32 * ATD_MASK_WORDS + 1 : 1];  // entries of the runs before it
+  __shared__ uint32_t rtot[GATHER ? 32 * ATD_MASK_WORDS / WAVE : 1];
+  // GATHER: the chunks of one tile read neighbouring runs of the same rows of A -- they run back to back on one XCD (workgroups
+  // are dealt to the eight XCDs round-robin), so a row's lines and pages are fetched once while its blocks pass
+  int rb, t;
+  if constexpr (GATHER) {   // grid: 8 x ceil(nct / 8) x nrb workgroups; XCD x takes the tiles t = x (mod 8), block after block
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    t = xcd + 8 * (j / nrb_all);
+    rb = j % nrb_all;
+    if (t >= nct) return;
+  } else {
+    rb = (int)(blockIdx.x / nct);
+    t = (int)(blockIdx.x % nct);
+  }
+  const int64_t chunk = (int64_t)rb * nct + t;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
   for (int i = threadIdx.x; i < QBLOCK_ROWS * ATD_MASK_WORDS; i += ATD_THREADS) mask[i] = 0u;
@@ -1648,6 +1705,23 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
     qoff_s[q + 1] = inc;                       // inclusive, within the wave
     if (lane == WAVE - 1) wtot[q / WAVE] = inc;
   }
+  if constexpr (GATHER) {
+    if (threadIdx.x < 32 * ATD_MASK_WORDS) {   // (the same first waves; tc <= 320)
+      const int i = threadIdx.x, lane = i & (WAVE - 1);
+      const int64_t bstride = (int64_t)nct * tc;
+      const int64_t lo = i < tc ? bnd[(int64_t)rb * bstride + (int64_t)t * tc + i] : 0;
+      const int64_t hi = i < tc ? bnd[(int64_t)(rb + 1) * bstride + (int64_t)t * tc + i] : 0;
+      run_lo[i] = lo;
+      uint32_t inc = hi > lo ? (uint32_t)(hi - lo) : 0u;
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t y = __shfl_up(inc, off);
+        if (lane >= off) inc += y;
+      }
+      run_pre[i + 1] = inc;
+      if (lane == WAVE - 1) rtot[i / WAVE] = inc;
+    }
+  }
   __syncthreads();
   if (threadIdx.x < Q_BLOCK_QUADS) {
     uint32_t add = 0;
@@ -1655,15 +1729,54 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
     qoff_s[threadIdx.x + 1] += add;
     if (threadIdx.x == 0) qoff_s[0] = 0u;
   }
+  if constexpr (GATHER) {
+    if (threadIdx.x < 32 * ATD_MASK_WORDS) {
+      uint32_t add = 0;
+      for (int w = 0; w < (int)threadIdx.x / WAVE; ++w) add += rtot[w];
+      run_pre[threadIdx.x + 1] += add;
+      if (threadIdx.x == 0) run_pre[0] = 0u;
+    }
+  }
   __syncthreads();
-  const int64_t b0 = bucket_off[chunk], b1 = bucket_off[chunk + 1];
-  Ent* dst = ent + chunk_off[chunk];
+  const int64_t b0 = GATHER ? 0 : bucket_off[chunk];
+  const int64_t b1 = GATHER ? (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)run_pre[32 * ATD_MASK_WORDS]) : bucket_off[chunk + 1];
   constexpr int HOLD = 10;   // entries a thread keeps in registers (chunks of up to 10240 entries: one read of the bucket)
+  // GATHER: the tile row of each of the first 10240 concatenated entries, written run by run into the (still unused) LDS
+  // image -- a thread then finds its entries with one LDS read each instead of a search over the runs
+  uint16_t* row_of = reinterpret_cast<uint16_t*>(stage);
+  if constexpr (GATHER) {
+    if (threadIdx.x < 3 * 32 * ATD_MASK_WORDS) {   // three threads per run
+      const uint32_t i = threadIdx.x / 3u;
+      const uint32_t k1 = min(run_pre[i + 1], (uint32_t)(HOLD * ATD_THREADS));
+      for (uint32_t k = run_pre[i] + threadIdx.x % 3u; k < k1; k += 3u) row_of[k] = (uint16_t)i;
+    }
+    __syncthreads();
+  }
+  // entry f of the chunk as {slot in the block << 9 | row in the tile, value}
+  auto fetch = [&](int64_t f, bool tabled) -> uint2 {
+    if constexpr (GATHER) {
+      int lo = 0;
+      if (tabled) {
+        lo = row_of[f];
+      } else {
+        int hi = 32 * ATD_MASK_WORDS - 1;   // the last row with run_pre[row] <= f
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if ((int64_t)run_pre[mid] <= f) lo = mid; else hi = mid - 1;
+        }
+      }
+      const int64_t e = run_lo[lo] + (f - (int64_t)run_pre[lo]);
+      return make_uint2(((uint32_t)(a_idx[e] - row0) << 9) | (uint32_t)lo, __float_as_uint(a_val[e]));
+    } else {
+      return bucket[f];
+    }
+  };
+  Ent* dst = ent + chunk_off[chunk];
   uint2 kv[HOLD];
 #pragma unroll
   for (int u = 0; u < HOLD; ++u) {
     const int64_t e = b0 + threadIdx.x + (int64_t)u * ATD_THREADS;
-    kv[u] = e < b1 ? bucket[e] : make_uint2(0xffffffffu, 0u);
+    kv[u] = e < b1 ? fetch(e, true) : make_uint2(0xffffffffu, 0u);
   }
 #pragma unroll
   for (int u = 0; u < HOLD; ++u)
@@ -1672,7 +1785,7 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
       atomicOr(&mask[slot * ATD_MASK_WORDS + (i >> 5)], 1u << (i & 31u));
     }
   for (int64_t e = b0 + threadIdx.x + (int64_t)HOLD * ATD_THREADS; e < b1; e += ATD_THREADS) {   // (longer chunks: the rest from memory)
-    const uint32_t key = bucket[e].x;
+    const uint32_t key = fetch(e, false).x;
     const uint32_t slot = key >> 9, i = key & 511u;
     atomicOr(&mask[slot * ATD_MASK_WORDS + (i >> 5)], 1u << (i & 31u));
   }
@@ -1685,65 +1798,101 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
     return rank;
   };
 #pragma unroll
-  for (int u = 0; u < HOLD; ++u) {   // kept beside the key (bits 19..27): the loop over the image below only places
-    if (kv[u].x != 0xffffffffu) kv[u].x |= rank_of(kv[u].x >> 9, kv[u].x & 511u) << 19;
+  for (int u = 0; u < HOLD; ++u) {   // the key becomes {place in the chunk (23 bits), row in the tile << 23}: the loop over the image below only places
+    if (kv[u].x != 0xffffffffu) {
+      const uint32_t slot = kv[u].x >> 9, i = kv[u].x & 511u;
+      kv[u].x = (qoff_s[slot >> 2] + rank_of(slot, i) * 4u + (slot & 3u)) | (i << 23);
+    }
     asm volatile("" ::: "memory");   // (one entry's LDS reads at a time: twelve unrolled copies in flight cost 128 VGPRs)
   }
-  for (int q0 = 0; q0 < nquads;) {
-    // the next run of quads whose segments fit the image
+  // The image is two halves: while one run of quads is written out (and summed), the next is assembled in the other half --
+  // one barrier per run.  Slots are written exactly once: entries by the threads that hold them, the padding behind a
+  // row's last entry by a thread per row.
+  const bool held = b1 - b0 <= (int64_t)HOLD * ATD_THREADS;   // no entry is ranked again below: the masks' LDS joins the image
+  const uint32_t HALF = held ? (uint32_t)(MASK_WORDS_ALL / 2 + ATD_STAGE_ENT) / 2u : (uint32_t)ATD_STAGE_ENT / 2u;   // (a quad holds at most 4 x 320 entries)
+  Ent* const image = held ? reinterpret_cast<Ent*>(pool) : stage;
+  for (int slot = threadIdx.x; slot < QBLOCK_ROWS; slot += ATD_THREADS) {   // entries of every row of the block in this tile
+    int len = 0;
+    for (int w = 0; w < ATD_MASK_WORDS; ++w) len += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
+    len_s[slot] = (uint16_t)len;
+  }
+  __syncthreads();
+  auto row_len = [&](int slot) { return (int)len_s[slot]; };
+  int half = 0;
+  for (int q0 = 0; q0 < nquads; half ^= 1) {
+    // the next run of quads whose segments fit half the image
     int q1 = q0 + 1;
     {
-      int lo = q0 + 1, hi = nquads;   // largest q1 with qoff[q1] - qoff[q0] <= ATD_STAGE_ENT
+      int lo = q0 + 1, hi = nquads;   // largest q1 with qoff[q1] - qoff[q0] <= HALF
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (qoff_s[mid] - qoff_s[q0] <= (uint32_t)ATD_STAGE_ENT) lo = mid; else hi = mid - 1;
+        if (qoff_s[mid] - qoff_s[q0] <= HALF) lo = mid; else hi = mid - 1;
       }
-      q1 = lo;
+      q1 = __builtin_amdgcn_readfirstlane(lo);   // (every thread finds the same run: keep it in scalar registers)
     }
-    const uint32_t o0 = qoff_s[q0], size = qoff_s[q1] - o0;
-    for (uint32_t i = threadIdx.x; i < size; i += ATD_THREADS) stage[i] = Ent{0u, 0.f};
-    __syncthreads();
+    Ent* st = image + (half ? HALF : 0u);
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)qoff_s[q0]);
+    const uint32_t size = (uint32_t)__builtin_amdgcn_readfirstlane((int)qoff_s[q1]) - o0;
+    for (int slot = 4 * q0 + (int)threadIdx.x; slot < 4 * q1; slot += ATD_THREADS) {   // padding
+      const uint32_t qo = qoff_s[slot >> 2], nsteps = (qoff_s[(slot >> 2) + 1] - qo) / 4u;
+      const uint32_t o = qo - o0 + (uint32_t)(slot & 3);
+#pragma clang loop vectorize(disable) unroll(disable)
+      for (uint32_t k = slot < nrows ? (uint32_t)row_len(slot) : 0u; k < nsteps; ++k) st[o + 4u * k] = Ent{0u, 0.f};
+    }
     auto place = [&](uint32_t slot, uint32_t i, uint32_t rank, uint32_t vbits) {
       const int q = (int)(slot >> 2);
       if (q < q0 || q >= q1) return;
       Ent x;
       x.off = i * (uint32_t)ldp_bytes;
       x.val = __uint_as_float(vbits);
-      stage[qoff_s[q] - o0 + rank * 4u + (slot & 3u)] = x;
+      st[qoff_s[q] - o0 + rank * 4u + (slot & 3u)] = x;
     };
 #pragma unroll
-    for (int u = 0; u < HOLD; ++u)
-      if (kv[u].x != 0xffffffffu) place((kv[u].x >> 9) & 1023u, kv[u].x & 511u, kv[u].x >> 19, kv[u].y);
+    for (int u = 0; u < HOLD; ++u) {   // (an empty hold has the place 2^23 - 1: never inside a run)
+      const uint32_t at = (kv[u].x & 0x7fffffu) - o0;
+      if (at < size) {
+        Ent x;
+        x.off = (kv[u].x >> 23) * (uint32_t)ldp_bytes;
+        x.val = __uint_as_float(kv[u].y);
+        st[at] = x;
+      }
+    }
     for (int64_t e = b0 + threadIdx.x + (int64_t)HOLD * ATD_THREADS; e < b1; e += ATD_THREADS) {
-      const uint2 x = bucket[e];
+      const uint2 x = fetch(e, false);
       const uint32_t slot = x.x >> 9, i = x.x & 511u;
       const int q = (int)(slot >> 2);
       if (q >= q0 && q < q1) place(slot, i, rank_of(slot, i), x.y);
     }
-    __syncthreads();
-    // (segments are multiples of 8 entries: 16-byte pieces)
+    __syncthreads();   // (this half is complete; the other one was read out before the previous barrier)
+    // (segments are multiples of 4 entries: 16-byte pieces)
     {
-      const uint4* src4 = reinterpret_cast<const uint4*>(stage);
+      const uint4* src4 = reinterpret_cast<const uint4*>(st);
       uint4* dst4 = reinterpret_cast<uint4*>(dst + o0);
       for (uint32_t i = threadIdx.x; i < size / 2; i += ATD_THREADS) dst4[i] = src4[i];
     }
-    const int slot = 4 * q0 + (int)threadIdx.x;
-    if (psum && slot < 4 * q1 && slot < nrows) {
-      int len = 0;
-#pragma unroll
-      for (int w = 0; w < ATD_MASK_WORDS; ++w) len += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
-      const uint32_t o = qoff_s[slot >> 2] - o0 + (uint32_t)(slot & 3);
-      double a = 0, b = 0;
-      for (int k = 0; k < len; ++k) {
-        const double v = (double)stage[o + 4u * k].val;
-        a += v;
-        b += v * v;
+    if (psum) {
+      // two threads per row: the entries at even and at odd places of its segment, added in stored order, then the two halves
+      const int pairs = 2 * (min(4 * q1, nrows) - 4 * q0);
+      for (int pr = (int)threadIdx.x; pr < pairs; pr += ATD_THREADS) {
+        const int slot = 4 * q0 + (pr >> 1), part = pr & 1;
+        const int len = row_len(slot);
+        const uint32_t o = qoff_s[slot >> 2] - o0 + (uint32_t)(slot & 3);
+        double a = 0, b = 0;
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int k = part; k < len; k += 2) {
+          const double v = (double)st[o + 4u * k].val;
+          a += v;
+          b += v * v;
+        }
+        a += __shfl_xor(a, 1);
+        b += __shfl_xor(b, 1);
+        if (part == 0) {
+          const int64_t row = perm ? (int64_t)perm[row0 + slot] : (int64_t)row0 + slot;
+          psum[(int64_t)t * n + row] = a;
+          psq[(int64_t)t * n + row] = b;
+        }
       }
-      const int64_t row = perm ? (int64_t)perm[row0 + slot] : (int64_t)row0 + slot;
-      psum[(int64_t)t * n + row] = a;
-      psq[(int64_t)t * n + row] = b;
     }
-    __syncthreads();
     q0 = q1;
   }
 }
@@ -1790,7 +1939,32 @@ struct AtDirectSrc {
   int64_t n2;
   DevBuf* scratch;         // buckets, bucket offsets, column map, partial sums
   double* stats;           // out: sum | sumsq per column of A (may be null)
+  const int64_t* bnd;      // gather fill: ends of every (A^T row block, A row) run for `nrb_nat` natural blocks (or null)
+  int64_t nrb_nat;
 };
+
+// rows per block of the DPP-fed sweep's operators, and the natural (unsorted) partition of `op_rows` rows: block count and
+// the split of the tile range over workgroups
+int dq_block_rows(int64_t op_rows) {
+  static const int dq_rows_env = getenv("SAPCA_DQ_BLOCK_ROWS") ? atoi(getenv("SAPCA_DQ_BLOCK_ROWS")) : 0;
+  return dq_rows_env == 512 || dq_rows_env == 1024 ? dq_rows_env : (op_rows >= 1024 * 16 ? 1024 : 512);
+}
+void natural_partition(int64_t op_rows, int nct, int block_rows, int64_t& nrb, int& nsplit) {
+  nrb = (op_rows + block_rows - 1) / block_rows;
+  nsplit = 1;
+  if (nrb >= 192) {
+    nrb = round_up(nrb, 256);
+  } else {
+    // few row blocks (A^T): split the tile range so that (blocks x splits) lands just under a
+    // multiple of the 256 CUs -- one workgroup per CU per round, no half-empty last round
+    static const int split_wgs_env = getenv("SAPCA_SPLIT_WGS") ? atoi(getenv("SAPCA_SPLIT_WGS")) : 0;
+    // 1024-row blocks fill a CU's LDS and registers alone: one workgroup per CU; the others run two per CU
+    const int64_t split_wgs = split_wgs_env > 0 ? split_wgs_env : (block_rows > 512 ? 256 : 512);
+    nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, split_wgs / nrb));
+    const int64_t nrb_fit = split_wgs / nsplit;
+    if (nrb_fit >= nrb && nrb_fit <= op_rows) nrb = nrb_fit;
+  }
+}
 
 template <typename VT>
 bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp& op, TiledBuffers& buf, hipStream_t s,
@@ -1823,25 +1997,13 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // with 64-column tiles keep that split, and take 1024-row blocks -- half the tile refills and barriers per entry --
   // when the operator has at least 16 of them (A^T of a tall matrix: the tile range is split over workgroups instead))
   const bool dq_candidate = f32 && quad && ldp == 64 && getenv("SAPCA_NO_DQ") == nullptr;
-  static const int dq_rows_env = getenv("SAPCA_DQ_BLOCK_ROWS") ? atoi(getenv("SAPCA_DQ_BLOCK_ROWS")) : 0;
-  const int block_rows = dq_candidate ? (dq_rows_env == 512 || dq_rows_env == 1024 ? dq_rows_env : (op_rows >= 1024 * 16 ? 1024 : 512))
+  const int block_rows = dq_candidate ? dq_block_rows(op_rows)
                          : quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
                                 : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
   int stage_cap = quad ? q_stage_bytes(tile_bytes) / (int)sizeof(E) - WAVE : STAGE_ENTRIES;
-  int64_t nrb = (op_rows + block_rows - 1) / block_rows;
+  int64_t nrb = 0;
   int nsplit = 1;
-  if (nrb >= 192) {
-    nrb = round_up(nrb, 256);
-  } else {
-    // few row blocks (A^T): split the tile range so that (blocks x splits) lands just under a
-    // multiple of the 256 CUs -- one workgroup per CU per round, no half-empty last round
-    static const int split_wgs_env = getenv("SAPCA_SPLIT_WGS") ? atoi(getenv("SAPCA_SPLIT_WGS")) : 0;
-    // 1024-row blocks fill a CU's LDS and registers alone: one workgroup per CU; the others run two per CU
-    const int64_t split_wgs = split_wgs_env > 0 ? split_wgs_env : (block_rows > 512 ? 256 : 512);
-    nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, split_wgs / nrb));
-    const int64_t nrb_fit = split_wgs / nsplit;
-    if (nrb_fit >= nrb && nrb_fit <= op_rows) nrb = nrb_fit;
-  }
+  natural_partition(op_rows, nct, block_rows, nrb, nsplit);
   // the bigger tile (fewer, longer tile steps, less quad padding) when the chunks are expected to leave room
   // in the smaller staging area; operators fed by the tile-major transposition keep the default split
   // (their tile count is fixed before the transposition runs)
@@ -2051,7 +2213,9 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     // bucket offsets, column -> (block, slot), the scatter of A's entries, one workgroup per chunk for the format
     const CsrView<float>& A = *direct->A;
     const size_t scan_bytes = 0;   // (d_raw was scanned together with the chunk sizes)
-    const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = round_up((size_t)A.nnz * sizeof(uint2), 256);
+    // SAPCA_AT_BUCKETS=1: the bucket route also where the gather fill applies (A/B runs; the two write the same bytes)
+    const bool gather = direct->bnd != nullptr && d_perm == nullptr && nrb == direct->nrb_nat && getenv("SAPCA_AT_BUCKETS") == nullptr;
+    const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = gather ? 0 : round_up((size_t)A.nnz * sizeof(uint2), 256);
     const size_t a_part = direct->stats ? round_up((size_t)nct * op_rows * sizeof(double), 256) : 0;
     const size_t a_scan = round_up(scan_bytes + 256, 256);
     char* base = static_cast<char*>(direct->scratch->ensure(a_col + a_bucket + 2 * a_part + a_scan + (size_t)nchunks * sizeof(uint32_t) + 256));
@@ -2059,14 +2223,22 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     uint2* d_bucket = reinterpret_cast<uint2*>(base + a_col);
     double* d_psum = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket) : nullptr;
     double* d_psq = direct->stats ? reinterpret_cast<double*>(base + a_col + a_bucket + a_part) : nullptr;
-    hipLaunchKernelGGL(atd_colmap_kernel, dim3((unsigned)((op_rows + 255) / 256)), dim3(256), 0, s, d_blk, (int)nrb, d_perm, op_rows,
-                       d_colmap);
-    uint32_t* d_cursor = reinterpret_cast<uint32_t*>(base + a_col + a_bucket + 2 * a_part + a_scan);
-    SAPCA_HIP(hipMemsetAsync(d_cursor, 0, (size_t)nchunks * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)std::min<int64_t>(round_up((A.rows + 3) / 4, 8), 4096)), dim3(256), 0, s, A.ptr,
-                       A.idx, A.val, A.rows, nct, tc, d_colmap, d_raw, d_cursor, d_bucket);
-    hipLaunchKernelGGL(atd_fill_kernel, dim3((unsigned)nchunks), dim3(ATD_THREADS), 0, s, d_bucket, d_raw, d_blk, d_perm, nct, ldp * 4,
-                       d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent, d_psum, d_psq, op_rows);
+    if (gather) {
+      // natural blocks are column ranges of A: every chunk reads its runs of A's rows itself (no buckets, no scatter pass)
+      hipLaunchKernelGGL(atd_fill_kernel<true>, dim3((unsigned)(8 * ((nct + 7) / 8) * nrb)), dim3(ATD_THREADS), 0, s, (const uint2*)nullptr,
+                         (const int64_t*)nullptr, d_blk, d_perm, nct, ldp * 4, d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent,
+                         d_psum, d_psq, op_rows, A.idx, A.val, direct->bnd, tc, (int)nrb);
+    } else {
+      hipLaunchKernelGGL(atd_colmap_kernel, dim3((unsigned)((op_rows + 255) / 256)), dim3(256), 0, s, d_blk, (int)nrb, d_perm, op_rows,
+                         d_colmap);
+      uint32_t* d_cursor = reinterpret_cast<uint32_t*>(base + a_col + a_bucket + 2 * a_part + a_scan);
+      SAPCA_HIP(hipMemsetAsync(d_cursor, 0, (size_t)nchunks * sizeof(uint32_t), s));
+      hipLaunchKernelGGL(atd_scatter_kernel, dim3((unsigned)std::min<int64_t>(round_up((A.rows + 3) / 4, 8), 4096)), dim3(256), 0, s, A.ptr,
+                         A.idx, A.val, A.rows, nct, tc, d_colmap, d_raw, d_cursor, d_bucket);
+      hipLaunchKernelGGL(atd_fill_kernel<false>, dim3((unsigned)nchunks), dim3(ATD_THREADS), 0, s, d_bucket, d_raw, d_blk, d_perm, nct, ldp * 4,
+                         d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent, d_psum, d_psq, op_rows,
+                         (const int32_t*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, tc, (int)nrb);
+    }
     if (direct->stats)
       hipLaunchKernelGGL(atd_stats_reduce_kernel, dim3((unsigned)((op_rows + 63) / 64)), dim3(1024), 0, s, d_psum, d_psq, op_rows, nct,
                          direct->stats, direct->stats + op_rows);
@@ -2084,7 +2256,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                          packed_rows, d_seg, d_blk, d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   } else if (staged_fill)
     hipLaunchKernelGGL(quad_fill_staged_kernel<float>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
-                       (size_t)qf_cap * sizeof(Ent) + ((size_t)5 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
+                       (size_t)qf_cap * sizeof(Ent) + ((size_t)7 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
                        d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (quad)
     hipLaunchKernelGGL(quad_fill_kernel<float>, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
@@ -2108,7 +2280,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
         hipLaunchKernelGGL((quad_fill_runs_kernel<false, double>), dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), 0, s, S.ptr, S.idx, S.val,
                            (const uint64_t*)nullptr, d_seg, d_blk, d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
     } else if (staged_fill) {
-      const size_t fill_lds = (size_t)qf_cap * sizeof(E) + ((size_t)5 * nct + 1) * sizeof(uint32_t);
+      const size_t fill_lds = (size_t)qf_cap * sizeof(E) + ((size_t)7 * nct + 1) * sizeof(uint32_t);
       static LdsAttrState attr;
       ensure_dynamic_lds(reinterpret_cast<const void*>(&quad_fill_staged_kernel<double>), fill_lds, attr);
       hipLaunchKernelGGL(quad_fill_staged_kernel<double>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), fill_lds, s, S.ptr, S.idx,
@@ -2144,16 +2316,28 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   const int64_t n2 = round_up(n, 2);
   // entry counts per (tile of A rows, column); their column totals are A^T's row lengths
   uint16_t* cnt16 = buf.seg.as<uint16_t>((size_t)nct * n2);   // (takes the place of the per-row tile index of the other routes)
+  // the natural partition of A^T's rows (the one the format takes unless its rows have to be sorted by length): the
+  // histogram pass leaves the ends of every (block, A row) run for the gather fill
+  int64_t nrb_nat = 0;
+  int nsplit_nat = 1;
+  natural_partition(n, nct, dq_block_rows(n), nrb_nat, nsplit_nat);
+  int64_t* bnd = nullptr;
+  if (getenv("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 256) {   // (the block arithmetic of the histogram pass)
+    const size_t bytes = (size_t)(nrb_nat + 1) * (size_t)nct * tc * sizeof(int64_t);
+    bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
+    SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
+  }
+  const size_t hist_lds = (size_t)n2 * 2;
   static LdsAttrState hist_attr;
-  ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), (size_t)n2 * 2, hist_attr);
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), hist_lds, hist_attr);
   hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 64 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),
-                     (size_t)n2 * 2, s, A.ptr, A.idx, m, nct, tc, n2, cnt16);
+                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, n, (int)nrb_nat, bnd);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
   launch_small_scan(at_ptr, nullptr, n, nullptr, s);
   SAPCA_HIP(hipGetLastError());
   CsrView<float> At;
   At.rows = n; At.cols = m; At.nnz = A.nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr;
-  AtDirectSrc src{&A, cnt16, n2, &scratch, stats};
+  AtDirectSrc src{&A, cnt16, n2, &scratch, stats, bnd, nrb_nat};
   return build_tiled_t<float>(At, false, ldp, op, buf, s, true, nullptr, true, false, &src);
 }
 

@@ -1307,6 +1307,43 @@ def test_bucket_route_to_the_transposed_format_on_skewed_columns(monkeypatch, sh
     np.testing.assert_allclose(out[0][1], want.mean, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", [(6000, 1500, 0.05), (40000, 3000, 0.02), (3000, 20000, 0.01), (4000, 2000, 0.5), (2500, 70, 0.2),
+                                  (1000, 40000, 0.004)])
+def test_gather_fill_and_bucket_route_write_the_same_format(monkeypatch, case):
+    """A^T's format in natural row order: every chunk gathers its runs of A's rows itself (default; the run ends come from
+    the histogram pass) or reads the bucket a scatter pass filled (SAPCA_AT_BUCKETS=1) -- the same bytes and the same
+    per-tile column sums, hence bit-identical fits.  Blocks of 512 and of 1024 rows, chunks above the ten entries a thread
+    holds in registers, rows without entries, a last tile with few rows; and the oracle's model."""
+    m, n, d = case
+    k, p, q = 6, 6, 2
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, d, seed=m + n, dtype=torch.float32))
+    A = mat(ptr, idx, val, m, n).tolil()
+    for r in (0, 17, m - 1):
+        A[r, :] = 0                                  # rows without entries (first and last of the matrix among them)
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    om = synth.gaussian_panel(n, k + p, 4).numpy()
+    dev = sapca.DeviceCsr(torch.as_tensor(A.indptr.astype(np.int64), device="cuda"), torch.as_tensor(A.indices.astype(np.int32), device="cuda"),
+                          torch.as_tensor(A.data.astype(np.float32), device="cuda"), (m, n))
+    out = []
+    for buckets in (False, True):
+        if buckets:
+            monkeypatch.setenv("SAPCA_AT_BUCKETS", "1")
+        else:
+            monkeypatch.delenv("SAPCA_AT_BUCKETS", raising=False)
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(dev).cpu().numpy()
+        out.append((pca.singular_values_(np.float64), pca.mean_(np.float64), pca.components_(np.float64), t))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    A64 = A.astype(np.float64)
+    want = O.fit(A64.indptr.astype(np.int64), A64.indices.astype(np.int64), A64.data, m, n, n_components=k, n_oversamples=p,
+                 n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(out[0][0], want.singular_values, rtol=2e-4)
+    np.testing.assert_allclose(out[0][1], want.mean, atol=1e-6)
+
+
 def test_bucket_route_on_a_half_dense_matrix(monkeypatch):
     """chunks of 80 000 entries (512 columns x 320 rows at density 0.5): the fill keeps ten entries per thread in registers
     and takes the rest of its bucket from memory; (row, tile) segments of up to 320 entries.  Against the transposition
