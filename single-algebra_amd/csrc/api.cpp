@@ -262,10 +262,15 @@ sapca_status transform_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz
       if (!h->fitted) throw Error(SAPCA_ERR_NOT_FITTED, "Must be fitted before transform!");
     }
     CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v, fit_first);
-    if (fit_first) Engine<T>::fit(*h, A);
-    T* d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * h->k, 1));
-    Engine<T>::transform(*h, A, d_out);
-    download_out(h, d_out, out, (size_t)(m * h->k));
+    if (fit_first) Engine<T>::fit(*h, A, true);   // (its host-side tail runs once the projection is queued)
+    try {
+      T* d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * h->k, 1));
+      Engine<T>::transform(*h, A, d_out);
+      download_out(h, d_out, out, (size_t)(m * h->k));
+    } catch (...) {
+      Engine<T>::finish_fit(*h);
+      throw;
+    }
   });
 }
 
@@ -282,7 +287,7 @@ sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t n
     SAPCA_CHECK(d_out != nullptr || m == 0, SAPCA_ERR_ARG, "null output buffer");
     CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
     if (fit_first) {
-      Engine<T>::fit(*h, A);
+      Engine<T>::fit(*h, A, true);
     } else if (static_cast<const void*>(v) != h->in_val.p) {
       // A separate transform call on caller-owned device arrays: pointer identity does not prove the matrix is the fitted
       // one (values edited in place, an allocator handing the same addresses to another matrix), so the preparation kept
@@ -291,7 +296,12 @@ sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t n
       // which only the library's own entry points modify (each of them drops the preparation).
       h->prep_key.valid = false;
     }
-    Engine<T>::transform(*h, A, d_out);
+    try {
+      Engine<T>::transform(*h, A, d_out);
+    } catch (...) {
+      Engine<T>::finish_fit(*h);   // (a fit whose tail was held back for the projection still completes)
+      throw;
+    }
   });
 }
 

@@ -805,10 +805,16 @@ void Engine<T>::fit_randomized(H& h) {
     Scope sc(h, C_SMALL);
     double* G = small;
     k::gram(X, n_used, ld, G, h.scratch2, s);
-    std::vector<double> g((size_t)ld * ld);
-    SAPCA_HIP(hipMemcpyAsync(g.data(), G, g.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipMemcpyAsync(&info_host, info, sizeof(int), hipMemcpyDeviceToHost, s));
+    // page-locked staging owned by the handle: G comes back and M goes out without the runtime's bounce buffers, and M
+    // outlives this call -- nothing here waits for the device after the eigensolver
+    const int ldk = (int)round_up(k, 16);
+    double* g = static_cast<double*>(h.small_host.ensure(((size_t)ld * ld + (size_t)ld * ldk + 2) * sizeof(double)));
+    double* M = g + (size_t)ld * ld;
+    int* info_pinned = reinterpret_cast<int*>(M + (size_t)ld * ldk);
+    SAPCA_HIP(hipMemcpyAsync(g, G, (size_t)ld * ld * sizeof(double), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(info_pinned, info, sizeof(int), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));
+    info_host = *info_pinned;
     std::vector<double> Gl((size_t)l * l), w, Vt;
     for (int i = 0; i < l; ++i)
       for (int j = 0; j < l; ++j) Gl[(size_t)i * l + j] = g[(size_t)i * ld + j];
@@ -822,20 +828,18 @@ void Engine<T>::fit_randomized(H& h) {
       SAPCA_CHECK(std::isfinite(w[i]), SAPCA_ERR_SVD, "Randomized SVD computation failed: non-finite singular value");
       sv[i] = std::sqrt(std::max(w[i], 0.0));
     }
-    const int ldk = (int)round_up(k, 16);
-    std::vector<double> M((size_t)ld * ldk, 0.0);
+    std::fill(M, M + (size_t)ld * ldk, 0.0);
     const double tiny = sv[0] * 1e-12;
     for (int j = 0; j < k; ++j) {
       if (!(sv[j] > tiny)) continue;   // numerically rank-deficient direction: a zero component, sigma ~ 0
       const double inv = 1.0 / sv[j];
       for (int i = 0; i < l; ++i) M[(size_t)i * ldk + j] = Vt[(size_t)j * l + i] * inv;
     }
-    SAPCA_HIP(hipMemcpyAsync(Mdev, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    SAPCA_HIP(hipMemcpyAsync(Mdev, M, (size_t)ld * ldk * sizeof(double), hipMemcpyHostToDevice, s));
     T* VtT = h.panel_w.as<T>((size_t)std::max<int64_t>(n_used, 1) * ldk);
     k::panel_gemm(X, n_used, ld, Mdev, ldk, VtT, s);
     T* comps = h.components_dev.as<T>((size_t)k * std::max<int64_t>(n_used, 1));
     k::flip_transpose(VtT, n_used, ldk, k, comps, h.scratch2, s);  // R13
-    SAPCA_HIP(hipStreamSynchronize(s));                            // M goes out of scope
     h.sing.assign(sv.begin(), sv.begin() + k);
     h.chol_regularised = info_host;
     return;
@@ -892,8 +896,9 @@ void Engine<T>::fit_lanczos(H& h) {
 // fit
 // ------------------------------------------------------------------------------------------
 template <typename T>
-void Engine<T>::fit(H& h, const CsrView<T>& A) {
+void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
   hipStream_t s = h.stream;
+  h.finish_pending = false;
   h.spans.clear();
   h.comm.host_ms = 0;
   h.timer.begin_collect(s, h.opt.collect_timings != 0);
@@ -939,6 +944,23 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
   h.n_cols = (uint64_t)A.cols;
   h.m_fit = h.m_global;
   h.dtype = kDtype;
+  h.fitted = true;
+  h.timer.stop(total_ev);
+  h.fit_total_ev = total_ev;
+  h.finish_pending = true;
+  // fit_transform: the host-side tail (statistics, timings: two waits for the device) runs once the projection is queued --
+  // the model the projection reads is all on the device by now
+  // (masked fits finish first: their projection asks the finished statistics whether its two sweeps would cancel, Q3)
+  if (!defer_finish || !h.mask.empty()) finish_fit(h);
+}
+
+template <typename T>
+void Engine<T>::finish_fit(H& h) {
+  if (!h.finish_pending) return;
+  h.finish_pending = false;
+  hipStream_t s = h.stream;
+  const int total_ev = h.fit_total_ev;
+  const int64_t n_used = (int64_t)h.n_used;
   // sparse/mod.rs:106-117: mean_ = col_sums / n when centring, zeros otherwise (the reference
   // allocates zeros(n_samples) there -- a length bug that is never read; n_cols zeros here).
   if (h.stats_pending) {   // (the copy was queued in prepare(); every path through the SVD engines has synchronised since)
@@ -959,8 +981,6 @@ void Engine<T>::fit(H& h, const CsrView<T>& A) {
     h.total_var = 0;
     for (uint64_t i = 0; i < h.k; ++i) h.total_var += h.expl_var[i];
   }
-  h.fitted = true;
-  h.timer.stop(total_ev);
   SAPCA_HIP(hipStreamSynchronize(s));
   collect_timings(h, true);
   if (total_ev >= 0) h.timings.fit_total_ms = h.timer.ms(total_ev);
@@ -1070,6 +1090,7 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     }
   }
   SAPCA_HIP(hipStreamSynchronize(s));
+  finish_fit(h);   // (fit_transform: the fit's host-side tail, held back until the projection was queued)
   collect_timings(h, false);
 }
 

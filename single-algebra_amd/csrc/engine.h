@@ -65,6 +65,9 @@ struct sapca_handle_s {
   // the column sums on the host (sum | sumsq | row count), copied asynchronously: single-rank fits read them at the end
   // of fit() instead of stalling the stream between the preparation and the first sweep
   sapca::PinnedBuf stats_host;
+  sapca::PinnedBuf small_host;    // the l x l Gram on its way to the host eigensolver, its factor on the way back
+  int fit_total_ev = -1;
+  bool finish_pending = false;    // fit() returned with its host-side tail still to run (fit_transform)
   sapca::PinnedBuf lanczos_host;  // alpha | beta of the Lanczos tridiagonal, read back at each convergence check
   bool stats_pending = false;
   int64_t stats_cols = 0;
@@ -114,7 +117,8 @@ struct Engine {
   static constexpr int kDtype = sizeof(T) == 8 ? 1 : 0;
   static void prepare(H& h, const CsrView<T>& A);
   static void finish_statistics(H& h);   // host side of R3 from stats_host (mean, total variance)
-  static void fit(H& h, const CsrView<T>& A);
+  static void fit(H& h, const CsrView<T>& A, bool defer_finish = false);
+  static void finish_fit(H& h);          // host-side tail of fit(): statistics, timings (after the last wait for the device)
   static void transform(H& h, const CsrView<T>& A, T* d_out);
   static void fit_randomized(H& h);
   static void fit_lanczos(H& h);
