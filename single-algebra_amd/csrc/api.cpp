@@ -465,14 +465,14 @@ template <typename T>
 sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci,
                        const T* v, const T* mu, uint64_t l, const T* In, T* Out, bool transposed) {
   return guarded(h, [&] {
-    SAPCA_CHECK(l >= 1 && l <= 128 && In && Out, SAPCA_ERR_ARG, "spmm: panel width must be in [1, 128]");
+    SAPCA_CHECK(l >= 1 && l <= (uint64_t)sapca::k::kMaxPanelWidth && In && Out, SAPCA_ERR_ARG, "spmm: panel width must be in [1, 1024]");
     CsrView<T> A = upload<T>(h, m, n, nnz, ro, ci, v);
     hipStream_t s = h->stream;
     // spmm_variant == 2 exercises the LDS-staged sweep on its own (f32 only): panels padded to 64/128
     const bool want_tiled = h->opt.spmm_variant == 2;
-    const int ld = want_tiled ? (l <= 64 ? 64 : 128) : (int)sapca::round_up((int64_t)l, 16);
+    const int ld = l > 128 ? (int)sapca::round_up((int64_t)l, 64) : want_tiled ? (l <= 64 ? 64 : 128) : (int)sapca::round_up((int64_t)l, 16);
     const uint64_t in_rows = transposed ? m : n, out_rows = transposed ? n : m;
-    T* stage = h->scratch2.as<T>(std::max<uint64_t>(in_rows * l, out_rows * l) + n + 2 * 128);
+    T* stage = h->scratch2.as<T>(std::max<uint64_t>(in_rows * l, out_rows * l) + n + 2 * (uint64_t)std::max(ld, 128));
     T* X = h->panel_x.as<T>(std::max<uint64_t>(in_rows, 1) * ld);
     T* Y = h->panel_y.as<T>(std::max<uint64_t>(out_rows, 1) * ld);
     SAPCA_HIP(hipMemcpyAsync(stage, In, in_rows * l * sizeof(T), hipMemcpyHostToDevice, s));
@@ -482,9 +482,10 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
       d_mu = h->mean_used_dev.as<T>(n);
       SAPCA_HIP(hipMemcpyAsync(d_mu, mu, n * sizeof(T), hipMemcpyHostToDevice, s));
     }
-    double* small = h->small.as<double>((size_t)6 * 128 * 128 + 64 + 4 * 128);
-    T* cvec = reinterpret_cast<T*>(small + (size_t)6 * 128 * 128 + 64);
-    T* svec = cvec + 128;
+    const size_t W = (size_t)std::max(ld, 128);   // (the layout of engine.cpp's SmallLayout)
+    double* small = h->small.as<double>(6 * W * W + 64 + 4 * W);
+    T* cvec = reinterpret_cast<T*>(small + 6 * W * W + 64);
+    T* svec = cvec + W;
     SAPCA_HIP(hipStreamSynchronize(s));
     if (!transposed) {
       if (mu) sapca::k::weighted_colsum(X, (int64_t)n, ld, d_mu, cvec, h->scratch, s);
@@ -526,10 +527,10 @@ sapca_status spmm_host(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, con
 template <typename T>
 sapca_status normalize_host(sapca_handle h, int32_t normalizer, uint64_t rows, uint64_t l, T* panel) {
   return guarded(h, [&] {
-    SAPCA_CHECK(l >= 1 && l <= 128 && panel && rows >= 1, SAPCA_ERR_ARG, "normalize: panel width must be in [1, 128]");
+    SAPCA_CHECK(l >= 1 && l <= (uint64_t)sapca::k::kMaxPanelWidth && panel && rows >= 1, SAPCA_ERR_ARG, "normalize: panel width must be in [1, 1024]");
     SAPCA_CHECK(normalizer >= 0 && normalizer <= 2, SAPCA_ERR_ARG, "unknown normalizer");
     hipStream_t s = h->stream;
-    const int ld = (int)sapca::round_up((int64_t)l, 16);
+    const int ld = (int)sapca::round_up((int64_t)l, l > 128 ? 64 : 16);
     T* stage = h->scratch.as<T>(rows * l);
     T* P = h->panel_y.as<T>(rows * ld);
     SAPCA_HIP(hipMemcpyAsync(stage, panel, rows * l * sizeof(T), hipMemcpyHostToDevice, s));
@@ -543,7 +544,7 @@ sapca_status normalize_host(sapca_handle h, int32_t normalizer, uint64_t rows, u
 template <typename T>
 sapca_status omega_host(sapca_handle h, uint64_t rows, uint64_t l, T* out) {
   return guarded(h, [&] {
-    SAPCA_CHECK(l >= 1 && l <= 128 && out, SAPCA_ERR_ARG, "omega: panel width must be in [1, 128]");
+    SAPCA_CHECK(l >= 1 && l <= (uint64_t)sapca::k::kMaxPanelWidth && out, SAPCA_ERR_ARG, "omega: panel width must be in [1, 1024]");
     const int ld = (int)sapca::round_up((int64_t)l, 16);
     T* P = h->panel_x.as<T>(std::max<uint64_t>(rows, 1) * ld);
     T* stage = h->scratch.as<T>(std::max<uint64_t>(rows * l, 1));

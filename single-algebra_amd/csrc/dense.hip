@@ -11,6 +11,10 @@
 // D: col = lane&15, row = (lane>>4) + 4*reg.
 #include "kernels.h"
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 namespace sapca {
 namespace k {
 
@@ -28,7 +32,7 @@ __device__ inline d4 mfma_f64(double a, double b, d4 c) { return __builtin_amdgc
 // reproducible) and unpacks the fragment layout into the full symmetric matrix.
 template <typename T, int NT>
 __global__ void __launch_bounds__(256)
-gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ slabs) {
+gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ slabs, const T* __restrict__ Pb = nullptr) {
   constexpr int NPAIR = NT * (NT + 1) / 2;
   extern __shared__ double lds[];  // NPAIR * 4 * 64
   const int lane = threadIdx.x & (WAVE - 1);
@@ -47,7 +51,7 @@ gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ 
   for (int d = 0; d < D; ++d) {
     const int64_t r = r0 + d * stride + g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) buf[d][t] = (r < rows) ? P[r * ld + 16 * t + c] : (T)0;
+    for (int t = 0; t < NT; ++t) buf[d][t] = (r < rows) ? ((Pb && t >= 4) ? Pb[r * ld + 16 * (t - 4) + c] : P[r * ld + 16 * t + c]) : (T)0;
   }
   for (; r0 < rows; r0 += D * stride) {
 #pragma unroll
@@ -57,7 +61,7 @@ gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ 
       for (int t = 0; t < NT; ++t) v[t] = (double)buf[d][t];
       const int64_t rn = r0 + (d + D) * stride + g;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) buf[d][t] = (rn < rows) ? P[rn * ld + 16 * t + c] : (T)0;
+      for (int t = 0; t < NT; ++t) buf[d][t] = (rn < rows) ? ((Pb && t >= 4) ? Pb[rn * ld + 16 * (t - 4) + c] : P[rn * ld + 16 * t + c]) : (T)0;
       int p = 0;
 #pragma unroll
       for (int ta = 0; ta < NT; ++ta)
@@ -549,9 +553,12 @@ template <> struct Quad<double> {
 // P[r0+i][16j+4g .. +3]; k-slot g of MFMA step (j, e) is panel column 16j+4g+e on both operands.
 template <typename T, int NTO>
 __global__ void __launch_bounds__(256)
-panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out) {
+panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out, int ldp_stride, int ldm_stride,
+                  int ldo_stride, int accumulate) {
+  // P: rows x ld at row stride ldp_stride; M: ld x ldo at row stride ldm_stride; out: rows x ldo at row stride ldo_stride
+  // (the wide-panel driver below walks 128-column blocks of a bigger product with these; accumulate: out += P M)
   extern __shared__ double Ms[];  // ld x ldo
-  for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) Ms[i] = M[i];
+  for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) Ms[i] = M[(i / ldo) * ldm_stride + (i % ldo)];
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = threadIdx.x / WAVE;
@@ -561,7 +568,7 @@ panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t r0 = tile * 16;
     const bool row_ok = r0 + i < rows;
-    const T* prow = P + (row_ok ? (r0 + i) : 0) * ld + 4 * g;
+    const T* prow = P + (row_ok ? (r0 + i) : 0) * ldp_stride + 4 * g;
     d4 acc[NTO];
 #pragma unroll
     for (int tb = 0; tb < NTO; ++tb) acc[tb] = d4{0, 0, 0, 0};
@@ -580,7 +587,10 @@ panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = r0 + g + 4 * reg;
-        if (r < rows) out[r * ldo + 16 * tb + i] = (T)acc[tb][reg];
+        if (r < rows) {
+          T* o = out + r * ldo_stride + 16 * tb + i;
+          *o = accumulate ? (T)((double)*o + acc[tb][reg]) : (T)acc[tb][reg];
+        }
       }
   }
 }
@@ -734,7 +744,8 @@ void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, h
 }
 
 template <typename T, int NTO>
-void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s) {
+void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, int ldp_stride = 0,
+                       int ldm_stride = 0, int ldo_stride = 0, int accumulate = 0) {
   const size_t lds = (size_t)ld * ldo * sizeof(double);
   static LdsAttrState attr;
   if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>), lds, attr);
@@ -742,14 +753,47 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
   int blocks = (int)((ntiles + 3) / 4);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((panel_gemm_kernel<T, NTO>), dim3(blocks), dim3(256), lds, s, P, rows, ld, M, ldo, out);
+  hipLaunchKernelGGL((panel_gemm_kernel<T, NTO>), dim3(blocks), dim3(256), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
+                     ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate);
 }
 
 }  // namespace
 
+// [G_II G_IJ; . G_JJ] of a 128 x 128 pair Gram -> the 64 x 64 blocks (I, I), (I, J), (J, I), (J, J) of the ld x ld matrix
+__global__ void gram_place_pair_kernel(const double* __restrict__ G2, int bi, int bj, int ld, double* __restrict__ G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 128 * 128) return;
+  const int r = i / 128, c = i % 128;
+  const int gr = (r < 64 ? 64 * bi : 64 * bj - 64) + r, gc = (c < 64 ? 64 * bi : 64 * bj - 64) + c;
+  G[(int64_t)gr * ld + gc] = G2[i];
+}
+
 template <typename T>
 void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s) {
-  SAPCA_CHECK(ld % 16 == 0 && ld >= 16 && ld <= 128, SAPCA_ERR_ARG, "panel width (n_components + n_oversamples) above 128 is not supported");
+  SAPCA_CHECK(ld % 16 == 0 && ld >= 16 && (ld <= 128 || (ld % 64 == 0 && ld <= kMaxPanelWidth)), SAPCA_ERR_ARG,
+              "gram: panel width must be a multiple of 16 up to 128, or of 64 up to 1024");
+  if (ld > 128) {
+    // wide panels: every pair (I < J) of 64-column blocks goes through the 128-wide kernel as the panel [P_I P_J]
+    // (a lone block pairs with itself); the diagonal blocks are written by several pairs, with the same bits each time
+    const int nb = ld / 64, npair = 36;
+    int nblocks = (int)((rows + 15) / 16);
+    if (nblocks > 512) nblocks = 512;
+    if (nblocks < 1) nblocks = 1;
+    double* slabs = scratch.as<double>((size_t)nblocks * npair * 256 + 128 * 128);
+    double* G2 = slabs + (size_t)nblocks * npair * 256;
+    for (int bi = 0; bi < nb; ++bi)
+      for (int bj = bi + 1; bj < nb; ++bj) {
+        constexpr int NPAIR8 = 36;
+        const size_t lds = (size_t)NPAIR8 * 256 * sizeof(double);
+        static LdsAttrState attr;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_kernel<T, 8>), lds, attr);
+        hipLaunchKernelGGL((gram_kernel<T, 8>), dim3(nblocks), dim3(256), lds, s, P + 64 * bi, rows, ld, slabs, P + 64 * bj);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, 8, 128, G2);
+        hipLaunchKernelGGL(gram_place_pair_kernel, dim3(64), dim3(256), 0, s, G2, bi, bj, ld, G);
+      }
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
   const int nt = ld / 16;
   const int npair = nt * (nt + 1) / 2;
   int nblocks = (int)((rows + 15) / 16);
@@ -770,8 +814,66 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
   SAPCA_HIP(hipGetLastError());
 }
 
+// l > 128: the factorisation runs on the host (the one-workgroup kernels keep the matrix in LDS); same pivot floor, same
+// outputs.  A wide panel is not the path this library is tuned for: it is here so that no (n_components, n_oversamples)
+// the reference accepts is refused.
+static void chol_inv_host(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
+  std::vector<double> g((size_t)ld * ld);
+  SAPCA_HIP(hipMemcpyAsync(g.data(), G, g.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  SAPCA_HIP(hipStreamSynchronize(s));
+  std::vector<double> a((size_t)l * l), r((size_t)ld * ld, 0.0), ri((size_t)ld * ld, 0.0), dinv((size_t)l);
+  for (int i = 0; i < l; ++i)
+    for (int j = 0; j < l; ++j) a[(size_t)i * l + j] = g[(size_t)i * ld + j];
+  double scale = 0;
+  for (int i = 0; i < l; ++i) scale = std::max(scale, std::fabs(a[(size_t)i * l + i]));
+  const double floor_v = scale * 1e-13 + 1e-300;
+  int bad = 0;
+  for (int kk = 0; kk < l; ++kk) {   // upper factor, right-looking: G = R^T R
+    double v = a[(size_t)kk * l + kk];
+    if (!(v > floor_v)) { v = floor_v; ++bad; }
+    v = std::sqrt(v);
+    a[(size_t)kk * l + kk] = v;
+    dinv[kk] = 1.0 / v;
+    double* rk = &a[(size_t)kk * l];
+    for (int j = kk + 1; j < l; ++j) rk[j] *= dinv[kk];
+    for (int i = kk + 1; i < l; ++i) {
+      const double rki = rk[i];
+      double* ai = &a[(size_t)i * l];
+      for (int j = i; j < l; ++j) ai[j] -= rki * rk[j];
+    }
+  }
+  // R^-1 (upper) by back substitution, row by row from the bottom: X[i][j] = -(sum_{i<t<=j} R[i][t] X[t][j]) / R[i][i]
+  for (int i = l - 1; i >= 0; --i) {
+    double* xi = &ri[(size_t)i * ld];
+    xi[i] = dinv[i];
+    for (int t = i + 1; t < l; ++t) {
+      const double rit = a[(size_t)i * l + t];
+      const double* xt = &ri[(size_t)t * ld];
+      for (int j = t; j < l; ++j) xi[j] -= rit * xt[j];
+    }
+    for (int j = i + 1; j < l; ++j) xi[j] *= dinv[i];
+    // (xi[j] accumulated -sum R[i][t] X[t][j]; the division by R[i][i] completes the row)
+  }
+  for (int i = 0; i < l; ++i)
+    for (int j = i; j < l; ++j) r[(size_t)i * ld + j] = a[(size_t)i * l + j];
+  SAPCA_HIP(hipMemcpyAsync(R, r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  SAPCA_HIP(hipMemcpyAsync(Rinv, ri.data(), ri.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  if (bad) {
+    int have = 0;
+    SAPCA_HIP(hipMemcpyAsync(&have, info, sizeof(int), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipStreamSynchronize(s));
+    have += bad;
+    SAPCA_HIP(hipMemcpyAsync(info, &have, sizeof(int), hipMemcpyHostToDevice, s));
+  }
+  SAPCA_HIP(hipStreamSynchronize(s));   // (the host vectors go out of scope)
+}
+
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
   static const bool general_only = getenv("SAPCA_CHOL_GENERAL") != nullptr;
+  if (l > 128) {
+    chol_inv_host(G, l, ld, R, Rinv, info, s);
+    return;
+  }
   if (l <= 64 && !general_only) {
     static LdsAttrState attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_blocked_kernel), kCholBlockedLds, attr);
@@ -793,11 +895,47 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
   SAPCA_HIP(hipGetLastError());
 }
 
+template <typename T, int NTO>
+static void panel_gemm_block(const T* P, int64_t rows, int kd, const double* M, int nd, T* out, hipStream_t s, int ldp, int ldm, int ldo, int acc) {
+  launch_panel_gemm<T, NTO>(P, rows, kd, M, nd, out, s, ldp, ldm, ldo, acc);
+}
+
 template <typename T>
-void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s) {
-  SAPCA_CHECK(ld % 16 == 0 && ldo % 16 == 0 && ld <= 128 && ldo <= 128 && ldo >= 16, SAPCA_ERR_ARG, "panel_gemm: unsupported panel width");
-  SAPCA_CHECK(out != P || ldo == ld, SAPCA_ERR_ARG, "panel_gemm: in-place needs ldo == ld");
+void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, bool upper) {
+  SAPCA_CHECK(ld % 16 == 0 && ldo % 16 == 0 && ldo >= 16 && ld <= kMaxPanelWidth && ldo <= kMaxPanelWidth, SAPCA_ERR_ARG,
+              "panel_gemm: unsupported panel width");
   if (rows == 0) return;
+  if (ld > 128 || ldo > 128) {
+    // wide: out[:, J] = sum_I P[:, I] M[I, J] over blocks of at most 128 columns, one launch per (I, J), accumulating over I
+    // (`upper`: M is upper triangular, the blocks below its diagonal are skipped).  Never in place.
+    SAPCA_CHECK(out != P, SAPCA_ERR_ARG, "panel_gemm: wide panels are not multiplied in place");
+    for (int j0 = 0; j0 < ldo; j0 += 128) {
+      const int nd = std::min(128, ldo - j0);
+      bool first = true;
+      for (int i0 = 0; i0 < ld; i0 += 128) {
+        const int kd = std::min(128, ld - i0);
+        if (upper && i0 >= j0 + nd) break;
+        const int acc = first ? 0 : 1;
+        first = false;
+        const T* Pb = P + i0;
+        const double* Mb = M + (size_t)i0 * ldo + j0;
+        T* ob = out + j0;
+        switch (nd / 16) {
+          case 1: panel_gemm_block<T, 1>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 2: panel_gemm_block<T, 2>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 3: panel_gemm_block<T, 3>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 4: panel_gemm_block<T, 4>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 5: panel_gemm_block<T, 5>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 6: panel_gemm_block<T, 6>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 7: panel_gemm_block<T, 7>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          default: panel_gemm_block<T, 8>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+        }
+      }
+    }
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
+  SAPCA_CHECK(out != P || ldo == ld, SAPCA_ERR_ARG, "panel_gemm: in-place needs ldo == ld");
   switch (ldo / 16) {
     case 1: launch_panel_gemm<T, 1>(P, rows, ld, M, ldo, out, s); break;
     case 2: launch_panel_gemm<T, 2>(P, rows, ld, M, ldo, out, s); break;
@@ -878,7 +1016,7 @@ void add_padding(const T* in, int64_t rows, int ncols, T* out, int ld, hipStream
 
 #define INSTANTIATE(T)                                                                            \
   template void gram<T>(const T*, int64_t, int, double*, DevBuf&, hipStream_t);                   \
-  template void panel_gemm<T>(const T*, int64_t, int, const double*, int, T*, hipStream_t);       \
+  template void panel_gemm<T>(const T*, int64_t, int, const double*, int, T*, hipStream_t, bool); \
   template void weighted_colsum<T>(const T*, int64_t, int, const T*, T*, DevBuf&, hipStream_t);   \
   template void rank1_subtract<T>(T*, int64_t, int, const T*, const T*, hipStream_t);             \
   template void flip_transpose<T>(const T*, int64_t, int, int, T*, DevBuf&, hipStream_t);         \

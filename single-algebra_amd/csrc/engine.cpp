@@ -23,7 +23,15 @@ namespace sapca {
 
 namespace {
 
-constexpr size_t kSmallDoubles = (size_t)6 * 128 * 128 + 64 + 4 * 128;
+// The handle's small f64 buffer: six ld x ld matrices (Gram, R^-1, scratch R, R1, R2, the small factor M), an int, and the
+// centring vectors c | s of the sweeps (T, W entries each) -- laid out for panels of W = max(ld, 128) columns.
+struct SmallLayout {
+  size_t W;
+  explicit SmallLayout(int ld) : W((size_t)std::max(ld, 128)) {}
+  size_t doubles() const { return 6 * W * W + 64 + 4 * W; }
+  size_t info_at() const { return 6 * W * W; }
+  size_t cvec_at() const { return 6 * W * W + 64; }
+};
 
 enum Cat { C_PREPARE, C_STATS, C_SPMM, C_SPMMT, C_ORTHO, C_SMALL, C_LANCZOS, C_TRANSFORM, C_COMM, C_COUNT };
 
@@ -109,7 +117,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
     const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
     const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
-    if (l >= 1 && l <= 128 && n_kept > 0) {
+    if (l >= 1 && l <= k::kMaxPanelWidth && n_kept > 0) {
       const int ldp = sizeof(T) == 4 ? k::tiled_geometry((int)l) : 64;
       const double row_bytes = (double)ldp * sizeof(T);
       const double tile_bytes = 80.0 * 1024.0, block_rows = row_bytes == 256.0 ? 512.0 : 256.0;
@@ -631,11 +639,12 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
   if (normalizer == SAPCA_NORM_NONE) return;
   hipStream_t s = h.stream;
   Scope sc(h, C_ORTHO);
-  double* base = h.small.as<double>(kSmallDoubles);
+  const SmallLayout lay(ld);
+  double* base = h.small.as<double>(lay.doubles());
   double* G = base;
   double* Rinv = base + (size_t)ld * ld;
   double* Rtmp = base + (size_t)2 * ld * ld;
-  int* info = reinterpret_cast<int*>(base + (size_t)6 * 128 * 128);
+  int* info = reinterpret_cast<int*>(base + lay.info_at());
   // QR -> CholeskyQR2 (orthonormal to working precision); LU -> one pass: a well-conditioned
   // basis of the same span, which is all the reference's LU normaliser provides.  Between power
   // iterations only the span matters (the next sweep re-mixes the basis), so the intermediate QR
@@ -647,7 +656,13 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
     if (sharded && h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(G, (uint64_t)ld * ld, 1, s); }
     double* Rout = pass == 0 ? (R1 ? R1 : Rtmp) : (R2 ? R2 : Rtmp);
     k::chol_inv(G, l, ld, Rout, Rinv, info, s);
-    k::panel_gemm(P, rows, ld, Rinv, ld, P, s);
+    if (ld <= 128) {
+      k::panel_gemm(P, rows, ld, Rinv, ld, P, s);
+    } else {   // wide panels: block by block into a second panel, then back (R^-1 is upper triangular)
+      T* Q = h.panel_wide.as<T>((size_t)std::max<int64_t>(rows, 1) * ld);
+      k::panel_gemm(P, rows, ld, Rinv, ld, Q, s, true);
+      SAPCA_HIP(hipMemcpyAsync(P, Q, (size_t)rows * ld * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
   }
 }
 
@@ -662,13 +677,15 @@ void Engine<T>::fit_randomized(H& h) {
   const int k = (int)h.opt.n_components;
   const int64_t l_req = (int64_t)h.opt.n_components + (int64_t)h.opt.n_oversamples;
   const int l = (int)std::min<int64_t>(l_req, std::min<int64_t>((int64_t)h.m_global, n_used));
-  SAPCA_CHECK(l <= 128, SAPCA_ERR_ARG, "n_components + n_oversamples above 128 is not supported");
+  SAPCA_CHECK(l <= k::kMaxPanelWidth, SAPCA_ERR_ARG, "n_components + n_oversamples above 1024 is not supported");
   const bool tiled = h.tiled_a.valid && h.tiled_at.valid;
   // The panel leading dimension enters the element counts of the all-reduces below, so with more than one rank it must
   // not depend on anything a rank decides locally (its own entry count against the staged-sweep floor, whether its
   // format build succeeded): row-sharded fits always use the staged sweep's panel geometry, whichever kernel a rank
   // picks for its shard (the row kernel takes any multiple of 16).
-  const int ld = (tiled || h.comm.active()) ? std::max(tiled ? h.tiled_a.ldp : 0, l <= 64 ? 64 : 128) : (int)round_up(l, 16);
+  // (above 128 columns every panel is a multiple of 64 wide: column passes of the sweeps, 64 / 128-column blocks of the dense kernels)
+  const int ld = l > 128 ? (int)round_up(l, 64)
+                         : (tiled || h.comm.active()) ? std::max(tiled ? h.tiled_a.ldp : 0, l <= 64 ? 64 : 128) : (int)round_up(l, 16);
   const int q = (int)h.opt.n_power_iterations;
   const int norm = h.opt.normalizer;
   const bool center = h.opt.center != 0;
@@ -676,13 +693,14 @@ void Engine<T>::fit_randomized(H& h) {
 
   T* X = h.panel_x.as<T>(((size_t)std::max<int64_t>(n_used, 1) + 1) * ld);   // + one row: the column sums ride along in the all-reduce
   T* Y = h.panel_y.as<T>((size_t)std::max<int64_t>(m, 1) * ld);
-  double* small = h.small.as<double>(kSmallDoubles);
+  const SmallLayout lay(ld);
+  double* small = h.small.as<double>(lay.doubles());
   double* R1 = small + (size_t)3 * ld * ld;
   double* R2 = small + (size_t)4 * ld * ld;
   double* Mdev = small + (size_t)5 * ld * ld;
-  int* info = reinterpret_cast<int*>(small + (size_t)6 * 128 * 128);
-  T* cvec = reinterpret_cast<T*>(small + (size_t)6 * 128 * 128 + 64);
-  T* svec = cvec + 128;
+  int* info = reinterpret_cast<int*>(small + lay.info_at());
+  T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
+  T* svec = cvec + lay.W;
   const T* mu = center ? h.mean_used_dev.ptr<T>() : nullptr;
   SAPCA_HIP(hipMemsetAsync(info, 0, sizeof(int), s));
 
@@ -1028,8 +1046,8 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     key.nnz = (uint64_t)A.nnz; key.mask_version = h.mask_version; key.dtype = kDtype; key.valid = true;
     const bool prepared = h.prep_key == key;
     // the fitted matrix's tile-major format serves the projection sweep too (one row block per workgroup)
-    const TiledOp* top = (prepared && h.tiled_a.valid && h.tiled_a.nsplit == 1 && k <= 128) ? &h.tiled_a : nullptr;
-    if (top) ldk = std::max(top->ldp, k <= 64 ? 64 : 128);
+    const TiledOp* top = (prepared && h.tiled_a.valid && h.tiled_a.nsplit == 1 && k <= k::kMaxPanelWidth) ? &h.tiled_a : nullptr;
+    if (top) ldk = k > 128 ? (int)round_up(k, 64) : std::max(top->ldp, k <= 64 ? 64 : 128);
     CsrView<T> Au;
     double* d_cnt = nullptr;
     if (prepared) {
@@ -1056,8 +1074,9 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
         if (h.comm.active()) h.comm.allreduce(d_cnt, (uint64_t)n, 1, s);
       }
     }
-    double* small = h.small.as<double>(kSmallDoubles);
-    T* cvec = reinterpret_cast<T*>(small + (size_t)6 * 128 * 128 + 64);
+    const SmallLayout lay(ldk);
+    double* small = h.small.as<double>(lay.doubles());
+    T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
     const T* mu = h.mean_used_dev.ptr<T>();
     const T* comps = h.components_dev.ptr<T>();
     T* W = h.panel_w.as<T>((size_t)n_used * ldk);

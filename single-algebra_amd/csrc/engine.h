@@ -92,7 +92,7 @@ struct sapca_handle_s {
   sapca::DevBuf drop_stats, drop_tmp;                              // their sums (sum | sumsq, full width) and the sort's work space
   sapca::DevBuf drop_col, drop_val;                                // the entries the compaction dropped, as (column, value) pairs
   sapca::DevBuf scratch, scratch2;
-  sapca::DevBuf panel_x, panel_y, panel_w;
+  sapca::DevBuf panel_x, panel_y, panel_w, panel_wide;   // (panel_wide: the out-of-place product of a panel wider than 128 columns)
   sapca::DevBuf small;                                           // G, R1, R2, Rinv, M, cvec, svec, info
   sapca::DevBuf stats;                                           // sum, sumsq, cnt (f64, n each)
   sapca::DevBuf mean_used_dev, o2m_dev, sel_rows_dev;

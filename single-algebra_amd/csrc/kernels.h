@@ -145,7 +145,11 @@ void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy,
                 hipStream_t s);
 
 // ---- dense.hip -------------------------------------------------------------------------
-// G = P^T P (ld x ld, f64, full symmetric) for a rows x ld panel with ld % 16 == 0, ld <= 128.
+// widest panel (n_components + n_oversamples, padded) the dense kernels take: up to 128 columns in one launch, beyond that in
+// blocks of 64 / 128 columns (correct, not tuned)
+constexpr int kMaxPanelWidth = 1024;
+
+// G = P^T P (ld x ld, f64, full symmetric) for a rows x ld panel with ld % 16 == 0 (ld <= 128) or ld % 64 == 0 (ld <= 1024).
 template <typename T>
 void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s);
 // Upper Cholesky G = R^T R on the leading l x l block, Rinv = R^{-1}; both ld x ld, zero padded.
@@ -154,7 +158,7 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
 // out[rows x ldo] = P[rows x ld] * M[ld x ldo]  (M f64, row-major, ldo % 16 == 0); out may alias P
 // when ldo == ld.
 template <typename T>
-void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s);
+void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, bool upper = false);
 // out[j] = sum_r w[r] P[r][j]  (w null => ones), j < ld, f64 accumulation.
 template <typename T>
 void weighted_colsum(const T* P, int64_t rows, int ld, const T* w, T* out, DevBuf& scratch, hipStream_t s);

@@ -256,7 +256,7 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
   if (A.rows == 0) return;
   if constexpr (sizeof(T) == 4) {
     // variant 1 forces the row kernel; otherwise the LDS-staged sweep runs whenever its format exists
-    const bool geom_ok = tiled && tiled->elem == 4 && (tiled->ldp == ldx || (tiled->fmt == 1 && tiled->ldp == 64 && ldx == 128));
+    const bool geom_ok = tiled && tiled->elem == 4 && (tiled->ldp == ldx || (tiled->fmt == 1 && tiled->ldp == 64 && ldx % 64 == 0));
     if (variant != 1 && tiled && tiled->valid && geom_ok && tiled->rows == A.rows && tiled->cols == A.cols) {
       spmm_tiled(*tiled, reinterpret_cast<const float*>(X), ldx, reinterpret_cast<float*>(Y), ldy, ncols,
                  reinterpret_cast<const float*>(cvec), scratch, s);
@@ -264,7 +264,7 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
     }
   } else {
     // f64: 64-column tile geometry (512-byte rows), 128-column panels in two passes
-    if (variant != 1 && tiled && tiled->valid && tiled->elem == 8 && (tiled->ldp == ldx || 2 * tiled->ldp == ldx) && tiled->rows == A.rows &&
+    if (variant != 1 && tiled && tiled->valid && tiled->elem == 8 && ldx % tiled->ldp == 0 && tiled->rows == A.rows &&
         tiled->cols == A.cols) {
       spmm_tiled(*tiled, reinterpret_cast<const double*>(X), ldx, reinterpret_cast<double*>(Y), ldy, ncols,
                  reinterpret_cast<const double*>(cvec), scratch, s);

@@ -291,7 +291,7 @@ bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   return true;
 }
 
-bool dq_usable(const TiledOp& op, int ldx) { return op.dq && (ldx == 64 || ldx == 128); }
+bool dq_usable(const TiledOp& op, int ldx) { return op.dq && ldx >= 64 && ldx % 64 == 0; }   // (wider panels: column passes of 64)
 
 void launch_dq_f64(const TiledOp& op, const double* X, int ldx, double* out, int ldo, int ncols, const double* cvec, hipStream_t s) {
   static LdsAttrState attr;

@@ -2359,7 +2359,7 @@ int tiled_tile_count(int64_t cols, int ldp) {
 void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
                 hipStream_t s) {
   SAPCA_CHECK(op.valid && op.elem == 4, SAPCA_ERR_ARG, "tiled sweep: operator not built");
-  SAPCA_CHECK(ldx == op.ldp || (op.fmt == 1 && op.ldp == 64 && ldx == 128), SAPCA_ERR_ARG,
+  SAPCA_CHECK(ldx == op.ldp || (op.fmt == 1 && op.ldp == 64 && ldx % 64 == 0), SAPCA_ERR_ARG,
               "tiled sweep: panel leading dimension does not match the operator's tile geometry");
   static const int mode = getenv("SAPCA_TILED_MODE") ? atoi(getenv("SAPCA_TILED_MODE")) : 0;  // ablation switches (debug)
   // A 128-wide panel over the 64-wide tile geometry goes through in two column passes: twice the entry
@@ -2456,7 +2456,7 @@ void spmm_tiled_piece(const TiledOp& op, int piece, int npieces, int wgs, int64_
 void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
                 hipStream_t s) {
   SAPCA_CHECK(op.valid && op.elem == 8 && op.fmt == 1, SAPCA_ERR_ARG, "tiled sweep: no f64 operator built");
-  SAPCA_CHECK(ldx == op.ldp || ldx == 2 * op.ldp, SAPCA_ERR_ARG,
+  SAPCA_CHECK(ldx >= op.ldp && ldx % op.ldp == 0, SAPCA_ERR_ARG,
               "tiled sweep: panel leading dimension does not match the operator's tile geometry");
   double* part = op.nsplit > 1 ? scratch.as<double>((size_t)op.nsplit * op.rows * op.ldp) : nullptr;
   const int passes = ldx / op.ldp;   // 128-column f64 panels: two column passes, as for f32

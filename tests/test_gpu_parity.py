@@ -1154,10 +1154,12 @@ def test_f64_wide_panel_fit_through_the_staged_sweep():
 
 
 def test_panel_width_limit_is_an_error():
-    ptr, idx, val = csr_np(synth.flat_csr(400, 300, 0.1, seed=2, dtype=torch.float32))
-    pca = _builder(120, 10, 1).build()
-    with pytest.raises(L.SapcaError, match="above 128") as e:
-        pca.fit(mat(ptr, idx, val, 400, 300))
+    """panels of up to 1024 columns are taken (the reference has no limit: above 128 the dense steps run block-wise);
+    beyond that the fit is refused with an argument error, not a crash"""
+    ptr, idx, val = csr_np(synth.flat_csr(1500, 1400, 0.05, seed=2, dtype=torch.float32))
+    pca = _builder(1020, 10, 1).build()
+    with pytest.raises(L.SapcaError, match="above 1024") as e:
+        pca.fit(mat(ptr, idx, val, 1500, 1400))
     assert e.value.status == L.ERR_ARG
 
 
@@ -1556,3 +1558,101 @@ def test_rows_sorted_by_length_on_a_skewed_matrix(monkeypatch):
     for o in outs[1:]:
         np.testing.assert_allclose(o[0], outs[0][0], rtol=1e-6)
         np.testing.assert_allclose(o[1], outs[0][1], atol=1e-4 * np.abs(outs[0][1]).max())
+
+
+# ------------------------------------------------------------------ panels wider than 128 columns
+# (the reference puts no limit on n_components + n_oversamples: sweeps in column passes of 64, the dense steps in blocks of
+#  64 / 128 columns, the Cholesky factor on the host -- correct, not tuned)
+@pytest.mark.parametrize("l", [129, 150, 192, 200, 270])
+def test_normalizer_on_panels_wider_than_128_columns(session, l):
+    P = synth.gaussian_panel(3000, l, 5).numpy().astype(np.float64)
+    P *= np.logspace(0, 2, l)[None, :]
+    Q = session.normalize_panel(P, PIN.QR)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(l), atol=5e-11)
+    q_ref, _ = np.linalg.qr(P)
+    assert O.subspace_angle(Q.T, q_ref.T) < 1e-9
+    Rm = Q.T @ P
+    assert np.allclose(np.tril(Rm, -1), 0, atol=1e-8 * np.abs(Rm).max()) and np.all(np.diag(Rm) > 0)
+    Qf = session.normalize_panel(P.astype(np.float32), PIN.QR).astype(np.float64)
+    np.testing.assert_allclose(Qf.T @ Qf, np.eye(l), atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype,l", [(np.float32, 150), (np.float32, 260), (np.float64, 150)])
+def test_sweeps_on_panels_wider_than_128_columns(session, session_tiled, dtype, l):
+    """both sweep kernels, A and A^T, with and without the centring vector"""
+    m, n = 5000, 1300
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, 0.05, seed=6, dtype=torch.float32 if dtype == np.float32 else torch.float64))
+    X = synth.gaussian_panel(n, l, 3).numpy().astype(dtype)
+    Yin = synth.gaussian_panel(m, l, 4).numpy().astype(dtype)
+    mu = (np.arange(n) % 7 / 7.0).astype(dtype)
+    A64 = mat(ptr, idx, val, m, n).astype(np.float64)
+    tol = 2e-5 if dtype == np.float32 else 1e-11
+    for sess in (session, session_tiled):
+        a = sess.spmm(ptr, idx, val, m, n, X)
+        want = A64 @ X.astype(np.float64)
+        np.testing.assert_allclose(a, want, atol=tol * np.abs(want).max())
+        ac = sess.spmm(ptr, idx, val, m, n, X, mu)
+        want_c = want - np.outer(np.ones(m), mu.astype(np.float64) @ X.astype(np.float64))
+        np.testing.assert_allclose(ac, want_c, atol=20 * tol * np.abs(want).max())
+        b = sess.spmm(ptr, idx, val, m, n, Yin, None, transposed=True)
+        want_t = A64.T @ Yin.astype(np.float64)
+        np.testing.assert_allclose(b, want_t, atol=tol * np.abs(want_t).max())
+
+
+@pytest.mark.parametrize("dtype,variant,k,p,shape", [(np.float32, 2, 140, 12, (8000, 2800, 0.20, 14.0, 11.5, 2.0)),
+                                                     (np.float32, 0, 140, 12, (8000, 2800, 0.20, 14.0, 11.5, 2.0)),
+                                                     (np.float64, 2, 136, 10, (8000, 2800, 0.20, 14.0, 11.5, 2.0)),
+                                                     (np.float32, 2, 250, 20, (10000, 3600, 0.15, 30.0, 26.0, 1.7))])
+def test_randomized_fit_with_more_than_128_panel_columns(dtype, variant, k, p, shape):
+    """n_components + n_oversamples = 146 .. 270 against the oracle on the same Omega: singular values, subspace, mean,
+    the projection (k > 128 columns of it), f32 on both sweep kernels and f64.  The matrices have a certified gap at k
+    (sigma_k / sigma_{k+1} of the centred operator, dense SVD)."""
+    m, n, dens, w_hi, w_lo, min_gap = shape
+    q = 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, dens, k, seed=77, centred=True, dtype=torch.float64, w_hi=w_hi, w_lo=w_lo))
+    D = mat(ptr, idx, val, m, n).toarray()
+    sv = np.linalg.svd(D - D.mean(axis=0), compute_uv=False)
+    assert sv[k - 1] >= min_gap * sv[k], "the generator left no gap at k"
+    om = synth.gaussian_panel(n, k + p, 5).numpy()
+    pca = _builder(k, p, q).spmm_variant(variant).build().set_omega(om)
+    t = pca.fit_transform(mat(ptr, idx, val.astype(dtype), m, n))
+    want = O.fit(ptr, idx, val.astype(dtype).astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    srel, ang = (1e-4, 1e-4) if dtype == np.float32 else (1e-9, 1e-8)
+    np.testing.assert_allclose(pca.singular_values_(np.float64), want.singular_values, rtol=srel)
+    assert O.subspace_angle(pca.components_(np.float64), want.components) < ang
+    np.testing.assert_allclose(pca.mean_(np.float64), want.mean, rtol=1e-5, atol=1e-7)
+    assert t.shape == (m, k)
+    wt = O.transform_sparse(ptr, idx, val.astype(dtype).astype(np.float64), m, n, pca.components_(np.float64), pca.mean_(np.float64), True)
+    np.testing.assert_allclose(t, wt, atol=(5e-4 if dtype == np.float32 else 1e-8) * max(1.0, float(np.abs(wt).max())))
+
+
+def test_masked_fit_and_lanczos_with_more_than_128_components():
+    """a masked randomized fit (l = 150 over the kept columns) against the oracle, and a Lanczos fit with 140 components
+    against the exact SVD of the dense operator"""
+    m, n, k, p, q = 8000, 3600, 138, 12, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.2, k, seed=78, centred=True, dtype=torch.float64, w_hi=14.0, w_lo=11.5))
+    mask = synth.bernoulli_mask(n, 0.8, 3).numpy()
+    D = mat(ptr, idx, val, m, n).toarray()[:, mask]
+    sv = np.linalg.svd(D - D.mean(axis=0), compute_uv=False)
+    if sv[k - 1] < 1.8 * sv[k]:
+        pytest.skip("no spectral gap at k under this mask: skipped, not loosened")
+    n_used = int(mask.sum())
+    om = synth.gaussian_panel(n_used, k + p, 6).numpy()
+    est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).random_seed(42)
+           .svd_method(SVDMethod.Random(p, q, PIN.QR)).spmm_variant(2).build().set_omega(om))
+    t = est.fit_transform(mat(ptr, idx, val.astype(np.float32), m, n))
+    want = O.fit(ptr, idx, val.astype(np.float32).astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q,
+                 omega=om, mask=mask)
+    np.testing.assert_allclose(est.singular_values_(np.float64), want.singular_values, rtol=1e-4)
+    assert O.subspace_angle(est.components_(np.float64), want.components) < 1e-4
+    assert t.shape == (m, k)
+    # Lanczos, uncentred (Q1), k = 140 on a smaller operator
+    m2, n2, k2 = 5000, 2800, 140
+    ptr2, idx2, val2 = csr_np(synth.gapped_csr(m2, n2, 0.2, k2, seed=79, centred=False, dtype=torch.float64, w_hi=14.0, w_lo=11.5))
+    lz = sapca.SparsePCABuilder.new().n_components(k2).svd_method(SVDMethod.Lanczos()).build()
+    t2 = lz.fit_transform(mat(ptr2, idx2, val2, m2, n2))
+    _, sv2, vt2 = np.linalg.svd(mat(ptr2, idx2, val2, m2, n2).toarray(), full_matrices=False)
+    np.testing.assert_allclose(lz.singular_values_(np.float64), sv2[:k2], rtol=1e-8)
+    if sv2[k2 - 1] >= 1.5 * sv2[k2]:
+        assert O.subspace_angle(lz.components_(np.float64), vt2[:k2]) < 1e-6
+    assert t2.shape == (m2, k2)
