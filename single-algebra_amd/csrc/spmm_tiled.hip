@@ -1484,14 +1484,14 @@ constexpr int ATD_MASK_WORDS = 10;        // 320 rows of a tile
 constexpr int ATD_HIST_THREADS = 512;   // (a tile per workgroup; eight waves: three or four tiles per CU at once, no second round at C2)
 constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave one workgroup per CU: sixteen waves then (C5: 100 KB)
 
-// With `bnd` (the gather fill below, natural row order of A^T): A^T's row blocks are the contiguous column ranges
-// [n b / nrb, n (b + 1) / nrb), and bnd[b][t * tc + i] becomes the position in A's arrays of the first entry of row
+// With `bnd` (the gather fill below, natural row order of A^T): A^T's row blocks are contiguous column ranges -- block b
+// holds the columns c with (int)((float)c * blk_scale) == b -- and bnd[b][t * tc + i] becomes the position in A's arrays of the first entry of row
 // t + i * nct whose column lies in block b or behind (b = 0..nrb; the row's end for the blocks it does not reach).  A row is
 // sorted by column, so these are the places where the block of the column changes: found in the registers that hold the
 // row's indices for the histogram anyway.
 __global__ void __launch_bounds__(ATD_HIST_THREADS_WIDE)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
-                uint16_t* __restrict__ cnt16, int64_t n, int nrb, int64_t* __restrict__ bnd) {
+                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, int64_t* __restrict__ bnd) {
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
   const int t = blockIdx.x;
   const int nw = (int)(n2 / 2);
@@ -1499,7 +1499,6 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
   for (int i = threadIdx.x; i < nw; i += nthreads) atd_h32[i] = 0u;
   __syncthreads();
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  const float inv_n = 1.0f / (float)n;
   const int64_t bstride = (int64_t)nct * tc;
   // (the next row's offsets are fetched while this row's indices are in flight: a row is one batch at C5's 500 entries)
   int64_t r = (int64_t)t + (int64_t)wave * nct;
@@ -1510,6 +1509,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
     const bool more = i + nwaves < tc && rn < m;
     const int64_t n0 = more ? ptr[rn] : 0, n1 = more ? ptr[rn + 1] : 0;
     int lastb = -1;   // block of the last entry seen in this row (wave-uniform)
+    int64_t* __restrict__ bnd_row = bnd ? bnd + (int64_t)t * tc + i : nullptr;
     for (int64_t base = e0; base < e1; base += 8 * WAVE) {   // eight loads in flight per lane (a wave-uniform trip count: the
       const int64_t eb = base + lane;                         //  boundary search below talks across lanes)
       int c[8];
@@ -1521,17 +1521,13 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
           const bool valid = c[u] >= 0;   // (valid lanes are a prefix of the wave)
           const unsigned long long valids = __ballot(valid);
           if (valids == 0ull) break;
-          // block of column c: the b with n b / nrb <= c < n (b + 1) / nrb (integer quotients), i.e. (c nrb + nrb - 1) / n;
-          // the numerator stays below 2^24 + 2^8 (c < 65536, nrb <= 256): a float quotient is off by one at most
-          const uint32_t x = __umul24((uint32_t)max(c[u], 0), (uint32_t)nrb) + (uint32_t)nrb - 1u;
-          uint32_t q = (uint32_t)((float)x * inv_n);
-          const int32_t rem = (int32_t)(x - __umul24(q, (uint32_t)n));
-          q = rem < 0 ? q - 1u : (rem >= (int32_t)n ? q + 1u : q);
-          const int b = (int)q;
+          // block of column c: (int)((float)c * scale) -- the partition is DEFINED by this expression (the host derives the
+          // block table from the same single-precision product: build_tiled_at_direct), so three instructions decide it
+          const int b = (int)((float)max(c[u], 0) * blk_scale);
           const int up = __builtin_amdgcn_update_dpp(0, b, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane l reads lane l - 1
           const int prev = lane == 0 ? lastb : up;
           if (valid && b != prev)
-            for (int j = prev + 1; j <= b; ++j) bnd[(int64_t)j * bstride + (int64_t)t * tc + i] = eb + u * WAVE;
+            for (int j = prev + 1; j <= b; ++j) bnd_row[(int64_t)__umul24((uint32_t)j, (uint32_t)bstride)] = eb + u * WAVE;   // (rows of A < 2^24)
           lastb = __builtin_amdgcn_readlane(b, __builtin_popcountll(valids) - 1);
         }
       }
@@ -1540,7 +1536,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
         if (c[u] >= 0) atomicAdd(&atd_h32[c[u] >> 1], 1u << (16 * (c[u] & 1)));   // (at most 320 rows per tile: no carry into the neighbour)
     }
     if (bnd)
-      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd[(int64_t)j * bstride + (int64_t)t * tc + i] = e1;
+      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd_row[(int64_t)j * bstride] = e1;
     r = rn;
     e0 = n0;
     e1 = n1;
@@ -1941,7 +1937,25 @@ struct AtDirectSrc {
   double* stats;           // out: sum | sumsq per column of A (may be null)
   const int64_t* bnd;      // gather fill: ends of every (A^T row block, A row) run for `nrb_nat` natural blocks (or null)
   int64_t nrb_nat;
+  const std::vector<int32_t>* blk_nat;   // ... and where those blocks start (float_blocks below)
 };
+
+// The natural blocks of the gather fill: block_of(c) = (int)((float)c * scale), with the scale taken down from nrb / n until
+// the last column lands in block nrb - 1.  Host and device evaluate the same IEEE single-precision product, so the table
+// below IS the device's partition; blocks differ from n / nrb columns by one at most and none is empty (scale <= 1).
+void float_blocks(int64_t n, int64_t nrb, std::vector<int32_t>& blk, float& scale) {
+  scale = (float)nrb / (float)n;
+  auto block_of = [&](int64_t c) { return (int64_t)(int)((float)(int)c * scale); };
+  while (block_of(n - 1) > nrb - 1) scale = std::nextafterf(scale, 0.0f);
+  blk.assign((size_t)nrb + 1, (int32_t)n);
+  int64_t b = 0;
+  blk[0] = 0;
+  for (int64_t c = 0; c < n; ++c) {
+    const int64_t bc = block_of(c);
+    while (b < bc) blk[(size_t)++b] = (int32_t)c;
+  }
+  while (b < nrb) blk[(size_t)++b] = (int32_t)n;   // (blocks past the last column: empty; cannot happen while nrb <= n)
+}
 
 // rows per block of the DPP-fed sweep's operators, and the natural (unsorted) partition of `op_rows` rows: block count and
 // the split of the tile range over workgroups
@@ -2102,6 +2116,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
         }
       }
       nrb = (int64_t)blk.size() - 1;
+    } else if (direct && direct->bnd && nrb == direct->nrb_nat) {
+      blk = *direct->blk_nat;   // (the partition the histogram pass recorded the run ends for)
     } else {
       blk.resize((size_t)nrb + 1);
       for (int64_t b = 0; b <= nrb; ++b) blk[(size_t)b] = (int32_t)(op_rows * b / nrb);
@@ -2322,7 +2338,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   int nsplit_nat = 1;
   natural_partition(n, nct, dq_block_rows(n), nrb_nat, nsplit_nat);
   int64_t* bnd = nullptr;
-  if (getenv("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 256) {   // (the block arithmetic of the histogram pass)
+  if (getenv("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096 && (int64_t)nct * tc < (1 << 24)) {   // (24-bit products in the histogram pass)
     const size_t bytes = (size_t)(nrb_nat + 1) * (size_t)nct * tc * sizeof(int64_t);
     bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
     SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
@@ -2330,14 +2346,17 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   const size_t hist_lds = (size_t)n2 * 2;
   static LdsAttrState hist_attr;
   ensure_dynamic_lds(reinterpret_cast<const void*>(&atd_hist_kernel), hist_lds, hist_attr);
+  std::vector<int32_t> blk_nat;
+  float blk_scale = 0.f;
+  if (bnd) float_blocks(n, nrb_nat, blk_nat, blk_scale);
   hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 64 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),
-                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, n, (int)nrb_nat, bnd);
+                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, blk_scale, (int)nrb_nat, bnd);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
   launch_small_scan(at_ptr, nullptr, n, nullptr, s);
   SAPCA_HIP(hipGetLastError());
   CsrView<float> At;
   At.rows = n; At.cols = m; At.nnz = A.nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr;
-  AtDirectSrc src{&A, cnt16, n2, &scratch, stats, bnd, nrb_nat};
+  AtDirectSrc src{&A, cnt16, n2, &scratch, stats, bnd, nrb_nat, &blk_nat};
   return build_tiled_t<float>(At, false, ldp, op, buf, s, true, nullptr, true, false, &src);
 }
 
