@@ -140,6 +140,7 @@ struct TiledOp {
 };
 struct TiledBuffers {
   DevBuf blk, seg, steps, wave_off, chunk_off, ent, tmp, misc, run, rank, perm, lens, dq_info, bounds;
+  PinnedBuf host;   // page-locked staging of the builder's small host <-> device exchanges
   // the DPP-fed sweep's tables are a latency-bound kernel over the counts: it runs on this stream beside the
   // bandwidth-bound fill (fork / join events on the build's own stream)
   hipStream_t aux = nullptr;

@@ -2060,18 +2060,22 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   uint32_t* d_perm = nullptr;
   std::vector<uint32_t> sorted_len;
   bool sort_rows = quad && !transposed && getenv("SAPCA_NO_ROWSORT") == nullptr;
+  // page-locked staging of this builder: [0] slots of the natural quads, [1..2] largest chunk | total, then the block table
+  int64_t* pinned = static_cast<int64_t*>(buf.host.ensure((size_t)(8 + 65536 + 2) * sizeof(int64_t)));
+  bool speculate = false;
   if (sort_rows && getenv("SAPCA_ROWSORT_ALWAYS") == nullptr) {
     // homogeneous rows pad little in their natural order: skip the sort (0.2 ms per operator at C2) unless the
-    // natural quads would hold 10 % more slots than entries
+    // natural quads would hold 10 % more slots than entries.  The count comes back with the chunk sizes below -- the
+    // natural order is assumed until then (one wait for the device instead of two); a matrix that needs the sort
+    // pays for a second round of counting.
     unsigned long long* d_slots = reinterpret_cast<unsigned long long*>(buf.misc.as<int64_t>(8)) + 4;
     SAPCA_HIP(hipMemsetAsync(d_slots, 0, sizeof(unsigned long long), s));
     hipLaunchKernelGGL(natural_quad_slots_kernel, dim3(grid_for((S.rows + 3) / 4, 256, 1024)), dim3(256), 0, s, S.ptr, S.rows, d_slots);
-    unsigned long long slots_nat = 0;
-    SAPCA_HIP(hipMemcpyAsync(&slots_nat, d_slots, sizeof(slots_nat), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipStreamSynchronize(s));
-    sort_rows = (double)slots_nat > 1.10 * (double)S.nnz;
+    SAPCA_HIP(hipMemcpyAsync(pinned, d_slots, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    speculate = true;
+    sort_rows = false;
   }
-  if (sort_rows) {
+  auto sort_now = [&] {
     uint32_t* d_len = buf.lens.as<uint32_t>((size_t)2 * S.rows);
     uint32_t* d_len_sorted = d_len + S.rows;
     uint32_t* d_iota = buf.perm.as<uint32_t>((size_t)2 * S.rows);
@@ -2084,7 +2088,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     sorted_len.resize((size_t)S.rows);
     SAPCA_HIP(hipMemcpyAsync(sorted_len.data(), d_len_sorted, sorted_len.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));
-  }
+  };
+  if (sort_rows) sort_now();
   // The entries of one (row block, tile) must fit the LDS staging.  Skewed inputs (a dense cluster
   // inside one tile) can exceed it: halve the rows per block and recount, a few times at most.
   int tiles_per_split = 0;
@@ -2128,7 +2133,12 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     d_wave_off = buf.wave_off.as<uint32_t>((size_t)nchunks * waves);
     if (quad) d_quad_off = buf.run.as<uint32_t>((size_t)nchunks * Q_BLOCK_QUADS);
     d_chunk = buf.chunk_off.as<int64_t>((size_t)nchunks + 1);
-    SAPCA_HIP(hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (blk.size() <= 2 * 65536) {   // (through the page-locked staging: the copy does not wait on a bounce buffer)
+      std::memcpy(pinned + 8, blk.data(), blk.size() * sizeof(int32_t));
+      SAPCA_HIP(hipMemcpyAsync(d_blk, pinned + 8, blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    } else {
+      SAPCA_HIP(hipMemcpyAsync(d_blk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
     if (transposed) {
       d_seg = buf.seg.as<int32_t>((size_t)S.rows * (nrb + 1));
       hipLaunchKernelGGL(bound_index_kernel, dim3(grid_for(S.rows * (nrb + 1), 256, 16384)), dim3(256), 0, s, S.ptr, S.idx,
@@ -2156,9 +2166,18 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     // the stored-entry counts) in one launch
     int64_t* d_max = buf.misc.as<int64_t>(8);
     launch_small_scan(d_chunk, d_raw, nchunks, d_max, s);
-    int64_t host[2] = {0, 0};
+    int64_t* host = pinned + 1;
     SAPCA_HIP(hipMemcpyAsync(host, d_max, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipStreamSynchronize(s));  // blk goes out of scope; sizes needed on the host
+    if (speculate) {
+      speculate = false;
+      if ((double)(unsigned long long)pinned[0] > 1.10 * (double)S.nnz) {   // the natural quads pad too much after all: sort, count again
+        sort_rows = true;
+        sort_now();
+        attempt = -1;
+        continue;
+      }
+    }
     max_chunk = host[0];
     total = host[1];
     if (getenv("SAPCA_DEBUG"))
