@@ -10,4 +10,6 @@ cp gpurun_out/r03_pmc_fetch_size.csv $out/r03_c2_dq_pmc_fetch_size.csv 2>/dev/nu
 cp gpurun_out/r03_pmc_write_size.csv $out/r03_c2_dq_pmc_write_size.csv 2>/dev/null
 ( cd /tmp && rm -rf /tmp/prof_c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c3 -o c3 -- python3 $GRAFT_REPO_ROOT/bench.py --workload c3 --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/$out/r03_c3_bench_profiled.json 2>/dev/null )
 cp $(find /tmp/prof_c3 -name "*kernel_stats.csv" | head -1) $out/r03_c3_kernel_stats.csv
+bash tools/timeline_fit.sh c2 > $out/r03_c2_step_gaps.txt 2>&1
+timeout -k 10 200 python3 tools/shape_time.py 200000 20000 0.03 200 10 4 3 > $out/r03_c2_matrix_k200.txt 2>/dev/null
 ls -la $out

@@ -11,7 +11,10 @@ idx=[i for i,r in enumerate(rows) if "atd_hist" in r["Kernel_Name"] or "pack_row
 i0=idx[-1]
 t0=int(rows[i0]["Start_Timestamp"])
 busy_end=t0; idle=0.0
-for r in rows[i0:]:
+last_sweep=max(i for i,r in enumerate(rows) if "spmm_dq" in r["Kernel_Name"] or "spmm_row" in r["Kernel_Name"] or "spmv" in r["Kernel_Name"])
+for n_,r in enumerate(rows[i0:]):
+    if i0+n_ == last_sweep+1:
+        print("== one step (first preparation kernel to the end of the projection sweep): %.1f us, GPU idle %.1f us ==" % ((busy_end-t0)/1e3, idle))
     s=int(r["Start_Timestamp"]); e=int(r["End_Timestamp"])
     gap=max(0,s-busy_end)/1e3; idle+=gap
     name=r["Kernel_Name"].replace("sapca::k::(anonymous namespace)::","").replace("sapca::(anonymous namespace)::","").replace("void ","")[:44]
