@@ -1046,7 +1046,9 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
     key.nnz = (uint64_t)A.nnz; key.mask_version = h.mask_version; key.dtype = kDtype; key.valid = true;
     const bool prepared = h.prep_key == key;
     // the fitted matrix's tile-major format serves the projection sweep too (one row block per workgroup)
-    const TiledOp* top = (prepared && h.tiled_a.valid && h.tiled_a.nsplit == 1 && k <= k::kMaxPanelWidth) ? &h.tiled_a : nullptr;
+    // (operators with few row blocks -- a shard of a strong-scaled fit -- split their tile range over workgroups: the sweep sums
+    //  the slabs itself; only the masked Q3 projection insists on an unsplit operator and checks that on its own)
+    const TiledOp* top = (prepared && h.tiled_a.valid && k <= k::kMaxPanelWidth) ? &h.tiled_a : nullptr;
     if (top) ldk = k > 128 ? (int)round_up(k, 64) : std::max(top->ldp, k <= 64 ? 64 : 128);
     CsrView<T> Au;
     double* d_cnt = nullptr;

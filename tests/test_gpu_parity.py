@@ -1656,3 +1656,32 @@ def test_masked_fit_and_lanczos_with_more_than_128_components():
     if sv2[k2 - 1] >= 1.5 * sv2[k2]:
         assert O.subspace_angle(lz.components_(np.float64), vt2[:k2]) < 1e-6
     assert t2.shape == (m2, k2)
+
+
+@pytest.mark.parametrize("semantics", ["reference", "centred"])
+def test_projection_through_an_operator_whose_tile_range_is_split(semantics):
+    """a matrix with few row blocks (a shard of a strong-scaled fit: 125k rows of C4 make 123 blocks) splits the tile range of
+    A's operator over workgroups; fit_transform's projection runs through that operator too (it used to fall back to the row
+    kernel: 2.0 instead of 0.55 ms on such a shard) -- against the oracle's projection, unmasked and masked"""
+    m, n, k, p, q = 30000, 2500, 8, 6, 2
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.06, k, seed=21, dtype=torch.float32))
+    om = synth.gaussian_panel(n, k + p, 3).numpy()
+    b = _builder(k, p, q).spmm_variant(2)
+    if semantics == "centred":
+        b = b.transform_semantics(L.TRANSFORM_CENTERED)
+    pca = b.build().set_omega(om)
+    t = pca.fit_transform(mat(ptr, idx, val, m, n))
+    comps, mean = pca.components_(np.float64), pca.mean_(np.float64)
+    if semantics == "reference":
+        want = O.transform_sparse(ptr, idx, val.astype(np.float64), m, n, comps, mean, True)      # Q2
+    else:
+        want = (mat(ptr, idx, val.astype(np.float64), m, n).toarray() - mean[None, :]) @ comps.T
+    np.testing.assert_allclose(t, want, atol=5e-4 * max(1.0, float(np.abs(want).max())))
+    t2 = pca.transform(mat(ptr, idx, val, m, n))
+    np.testing.assert_allclose(t2, t, atol=5e-4 * max(1.0, float(np.abs(t).max())))
+    mask = synth.bernoulli_mask(n, 0.8, 3).numpy()
+    est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).random_seed(42)
+           .svd_method(SVDMethod.Random(p, q, PIN.QR)).spmm_variant(2).build())
+    tm = est.fit_transform(mat(ptr, idx, val, m, n))
+    wm = O.transform_masked_fast(ptr, idx, val.astype(np.float64), m, n, est.components_(np.float64), est.mean_(np.float64), True, mask)
+    np.testing.assert_allclose(tm, wm, atol=5e-4 * max(1.0, float(np.abs(wm).max())))
