@@ -80,7 +80,7 @@ typedef struct sapca_options {
   uint8_t collect_timings;       /* record per-stage HIP-event timings (sapca_get_timings)      */
   uint8_t reserved0;
   int32_t method;                /* sapca_method, default SAPCA_LANCZOS                         */
-  uint64_t n_oversamples;        /* SVDMethod::Random.n_oversamples                             */
+  uint64_t n_oversamples;        /* SVDMethod::Random.n_oversamples (n_components + this: at most 1024; above 128 block-wise, untuned) */
   uint64_t n_power_iterations;   /* SVDMethod::Random.n_power_iterations                        */
   int32_t normalizer;            /* sapca_normalizer                                            */
   int32_t transform_semantics;   /* sapca_transform_semantics                                   */

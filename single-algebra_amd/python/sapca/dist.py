@@ -123,7 +123,8 @@ def init_comm(estimator, group=None, prefer="rccl", stage_through_host=False):
                 if any(o is None for o in outcome):
                     raise RuntimeError(f"ncclCommInitRank succeeded on some ranks only: {outcome}")
                 if rank == 0:
-                    print(f"sapca: RCCL initialisation failed on every rank ({outcome[0]}); using torch.distributed", flush=True)
+                    import sys
+                    print(f"sapca: RCCL initialisation failed on every rank ({outcome[0]}); using torch.distributed", file=sys.stderr, flush=True)
     estimator.comm_set_callback(world, rank, torch_allreduce_callback(group, stage_through_host))
     return "torch"
 
