@@ -823,9 +823,29 @@ void Engine<T>::fit_randomized(H& h) {
     Scope sc(h, C_SMALL);
     double* G = small;
     k::gram(X, n_used, ld, G, h.scratch2, s);
+    const int ldk = (int)round_up(k, 16);
+    if (k::sym_eig_device_ok(l)) {
+      // (opt-in experiment, SAPCA_EIG_DEVICE=1: slower than the host path below -- see sym_eig_device_ok)
+      // the eigenproblem stays on the device (one workgroup, parallel Jacobi: dense.hip) and writes the factor M itself:
+      // no wait for the host anywhere in the small SVD.  The singular values (and the solver's status) cross in page-locked
+      // memory behind everything else; finish_fit() reads them after the fit's last wait.
+      double* d_sigma = small + (size_t)ld * ld;                  // (the normaliser's R^-1 slot: free here)
+      int* d_status = reinterpret_cast<int*>(d_sigma + ld);
+      k::sym_eig_device(G, l, ld, k, ldk, Mdev, d_sigma, d_status, s);
+      double* host = static_cast<double*>(h.small_host.ensure(((size_t)l + 4) * sizeof(double)));
+      int* host_i = reinterpret_cast<int*>(host + l);
+      SAPCA_HIP(hipMemcpyAsync(host, d_sigma, (size_t)l * sizeof(double), hipMemcpyDeviceToHost, s));
+      SAPCA_HIP(hipMemcpyAsync(host_i, d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+      SAPCA_HIP(hipMemcpyAsync(host_i + 2, info, sizeof(int), hipMemcpyDeviceToHost, s));
+      T* VtT = h.panel_w.as<T>((size_t)std::max<int64_t>(n_used, 1) * ldk);
+      k::panel_gemm(X, n_used, ld, Mdev, ldk, VtT, s);
+      T* comps = h.components_dev.as<T>((size_t)k * std::max<int64_t>(n_used, 1));
+      k::flip_transpose(VtT, n_used, ldk, k, comps, h.scratch2, s);  // R13
+      h.sing_pending = l;
+      return;
+    }
     // page-locked staging owned by the handle: G comes back and M goes out without the runtime's bounce buffers, and M
     // outlives this call -- nothing here waits for the device after the eigensolver
-    const int ldk = (int)round_up(k, 16);
     double* g = static_cast<double*>(h.small_host.ensure(((size_t)ld * ld + (size_t)ld * ldk + 2) * sizeof(double)));
     double* M = g + (size_t)ld * ld;
     int* info_pinned = reinterpret_cast<int*>(M + (size_t)ld * ldk);
@@ -917,6 +937,7 @@ template <typename T>
 void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
   hipStream_t s = h.stream;
   h.finish_pending = false;
+  h.sing_pending = 0;
   h.spans.clear();
   h.comm.host_ms = 0;
   h.timer.begin_collect(s, h.opt.collect_timings != 0);
@@ -979,6 +1000,23 @@ void Engine<T>::finish_fit(H& h) {
   hipStream_t s = h.stream;
   const int total_ev = h.fit_total_ev;
   const int64_t n_used = (int64_t)h.n_used;
+  if (h.sing_pending) {   // the device eigensolver's singular values and status (fit_randomized)
+    const int l = h.sing_pending;
+    h.sing_pending = 0;
+    SAPCA_HIP(hipStreamSynchronize(s));
+    const double* host = static_cast<const double*>(h.small_host.p);
+    const int* host_i = reinterpret_cast<const int*>(host + l);
+    bool finite = true;
+    for (int i = 0; i < l; ++i) finite = finite && std::isfinite(host[i]);
+    if ((host_i[0] & 1) || (host_i[0] & 2) || !finite) {
+      h.fitted = false;
+      throw Error(SAPCA_ERR_SVD, (host_i[0] & 1) ? "Randomized SVD computation failed: eigensolver did not converge"
+                                                 : "Randomized SVD computation failed: non-finite singular value");
+    }
+    if (h.opt.verbose) fprintf(stderr, "sapca: device eigensolver of the %d x %d Gram: %d sweeps\n", l, l, host_i[1]);
+    h.sing.assign(host, host + h.k);
+    h.chol_regularised = host_i[2];
+  }
   // sparse/mod.rs:106-117: mean_ = col_sums / n when centring, zeros otherwise (the reference
   // allocates zeros(n_samples) there -- a length bug that is never read; n_cols zeros here).
   if (h.stats_pending) {   // (the copy was queued in prepare(); every path through the SVD engines has synchronised since)

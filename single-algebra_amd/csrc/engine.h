@@ -68,6 +68,7 @@ struct sapca_handle_s {
   sapca::PinnedBuf small_host;    // the l x l Gram on its way to the host eigensolver, its factor on the way back
   int fit_total_ev = -1;
   bool finish_pending = false;    // fit() returned with its host-side tail still to run (fit_transform)
+  int sing_pending = 0;           // l: the singular values of the device eigensolver are still on their way (read in finish_fit)
   sapca::PinnedBuf lanczos_host;  // alpha | beta of the Lanczos tridiagonal, read back at each convergence check
   bool stats_pending = false;
   int64_t stats_cols = 0;

@@ -155,6 +155,12 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
 // Upper Cholesky G = R^T R on the leading l x l block, Rinv = R^{-1}; both ld x ld, zero padded.
 // *info += number of pivots that had to be regularised.
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s);
+
+// Eigen-decomposition of the symmetric l x l matrix G (row stride ld) on the device, one workgroup (parallel Jacobi in LDS,
+// l <= 112): M (ld x ldk, zero padded) = leading k eigenvectors in columns, each divided by sigma_j = sqrt(lambda_j), in
+// descending order; sigma[0..l) = all of them; status[0] = 0 / 1 (not converged) | 2 (non-finite), status[1] = sweeps.
+bool sym_eig_device_ok(int l);
+void sym_eig_device(const double* G, int l, int ld, int k, int ldk, double* M, double* sigma, int* status, hipStream_t s);
 // out[rows x ldo] = P[rows x ld] * M[ld x ldo]  (M f64, row-major, ldo % 16 == 0); out may alias P
 // when ldo == ld.
 template <typename T>

@@ -1685,3 +1685,53 @@ def test_projection_through_an_operator_whose_tile_range_is_split(semantics):
     tm = est.fit_transform(mat(ptr, idx, val, m, n))
     wm = O.transform_masked_fast(ptr, idx, val.astype(np.float64), m, n, est.components_(np.float64), est.mean_(np.float64), True, mask)
     np.testing.assert_allclose(tm, wm, atol=5e-4 * max(1.0, float(np.abs(wm).max())))
+
+
+@pytest.mark.parametrize("l", [1, 2, 3, 7, 16, 33, 60, 61, 90, 111, 112, 113])
+def test_device_eigensolver_against_the_host_one(monkeypatch, l):
+    """the l x l Gram of the small SVD: parallel Jacobi in one workgroup on the device (l <= 112, SAPCA_EIG_DEVICE=1: an
+    experiment, four times slower than the default) against the host's Householder + QL (l = 113 takes the host on both runs) -- the same singular values to 1e-6 relative
+    (f32 panels upstream: both solvers see the same f64 Gram, and agree to ~1e-12 of sigma_0), the same subspace, the same
+    projection; odd l (a dummy index in the tournament), l = 1, and the oracle's numbers"""
+    m, n = 4000, 900
+    k = max(1, l - 4) if l > 8 else l
+    p, q = l - k, 1
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.08, min(k, 40), seed=l, dtype=torch.float32))
+    om = synth.gaussian_panel(n, l, 4).numpy()
+    out = []
+    for host in (False, True):
+        if host:
+            monkeypatch.delenv("SAPCA_EIG_DEVICE", raising=False)
+        else:
+            monkeypatch.setenv("SAPCA_EIG_DEVICE", "1")
+        pca = _builder(k, p, q).build().set_omega(om)
+        t = pca.fit_transform(mat(ptr, idx, val, m, n))
+        out.append((pca.singular_values_(np.float64), pca.components_(np.float64), t, pca.explained_variance_ratio(np.float64)))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-6, atol=1e-9 * out[1][0][0])
+    np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-5, atol=1e-9)
+    want = O.fit(ptr, idx, val.astype(np.float64), m, n, n_components=k, n_oversamples=p, n_power_iterations=q, omega=om)
+    np.testing.assert_allclose(out[0][0], want.singular_values, rtol=2e-4)
+    # the leading components (well separated in this generator) agree between the two solvers; so does the projection on them
+    j = min(k, 5)
+    assert O.subspace_angle(out[0][1][:j], out[1][1][:j]) < 1e-4
+    np.testing.assert_allclose(np.abs(out[0][2][:, :j]), np.abs(out[1][2][:, :j]), atol=2e-3 * np.abs(out[1][2]).max())
+
+
+def test_device_eigensolver_on_a_rank_deficient_gram(monkeypatch):
+    """more panel columns than the matrix has rank: the Gram has zero eigenvalues; the solver must converge (rotations against
+    rounding noise are skipped) and the surplus directions come out as zero components with sigma ~ 0"""
+    rng = np.random.default_rng(5)
+    m, n, r, k, p = 3000, 500, 6, 10, 6
+    U = rng.standard_normal((m, r)) * (rng.random((m, r)) < 0.2)
+    W = rng.standard_normal((r, n)) * (rng.random((r, n)) < 0.3)
+    D = (U @ W).astype(np.float32)
+    A = sp.csr_matrix(D)
+    A.sort_indices()
+    monkeypatch.setenv("SAPCA_EIG_DEVICE", "1")
+    pca = _builder(k, p, 1).center(False).build()
+    t = pca.fit_transform(A)
+    sv = pca.singular_values_(np.float64)
+    s_exact = np.linalg.svd(D.astype(np.float64), compute_uv=False)
+    np.testing.assert_allclose(sv[:r], s_exact[:r], rtol=1e-4)
+    assert np.all(sv[r:] <= 1e-3 * sv[0])
+    assert np.all(np.isfinite(t))
