@@ -1735,3 +1735,47 @@ def test_device_eigensolver_on_a_rank_deficient_gram(monkeypatch):
     np.testing.assert_allclose(sv[:r], s_exact[:r], rtol=1e-4)
     assert np.all(sv[r:] <= 1e-3 * sv[0])
     assert np.all(np.isfinite(t))
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_gather_fill_on_random_shapes_is_the_bucket_route_bit_for_bit(monkeypatch, seed):
+    """random shapes (1 to 500 tiles of A rows, 70 to 60 000 columns: block counts from a few to 64, blocks of 512 and of 1024
+    rows), densities from 0.2 % to 30 %, a few dense rows and empty rows thrown in: A^T's format through the gather fill and
+    through the bucket route must give bit-identical fits (same bytes, same per-tile column sums)"""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([300, 321, 2000, 5000, 20000, 60000, 160000]))
+    n = int(rng.choice([70, 600, 1023, 1025, 4000, 17000, 60000]))
+    dens = float(rng.choice([0.002, 0.01, 0.05, 0.3]))
+    if m * n > 4e8:                       # (the generator hashes every cell: keep the host side of the test short)
+        m = int(4e8 / n)
+    if m * n * dens > 1e7:
+        dens = 1e7 / (m * n)
+    if m * n * dens < 2000:
+        dens = min(0.5, 2000 / (m * n))
+    k, p, q = 5, 5, 1
+    ptr, idx, val = csr_np(synth.flat_csr(m, n, dens, seed=seed, dtype=torch.float32, device="cuda"))
+    A = mat(ptr, idx, val, m, n)
+    for r in rng.choice(m, 3, replace=False):                     # rows without entries
+        A.data[A.indptr[int(r)]:A.indptr[int(r) + 1]] = 0
+    A.eliminate_zeros()
+    if n <= 4000:                                                 # one dense row
+        r = int(rng.integers(m))
+        dense = sp.csr_matrix(rng.uniform(0.5, 1.5, (1, n)).astype(np.float32))
+        A = sp.vstack([A[:r], dense, A[r + 1:]]).tocsr()
+    A.sort_indices()
+    om = synth.gaussian_panel(n, k + p, 4).numpy()
+    dev = sapca.DeviceCsr(torch.as_tensor(A.indptr.astype(np.int64), device="cuda"), torch.as_tensor(A.indices.astype(np.int32), device="cuda"),
+                          torch.as_tensor(A.data.astype(np.float32), device="cuda"), (m, n))
+    out = []
+    for buckets in (False, True):
+        if buckets:
+            monkeypatch.setenv("SAPCA_AT_BUCKETS", "1")
+        else:
+            monkeypatch.delenv("SAPCA_AT_BUCKETS", raising=False)
+        pca = _builder(k, p, q).spmm_variant(2).build().set_omega(om)
+        t = pca.fit_transform(dev).cpu().numpy()
+        out.append((pca.singular_values_(np.float64), pca.mean_(np.float64), pca.components_(np.float64), t))
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+    want_mean = np.asarray(A.astype(np.float64).sum(axis=0)).ravel() / m
+    np.testing.assert_allclose(out[0][1], want_mean, rtol=1e-6, atol=1e-9)
