@@ -88,6 +88,73 @@ gram_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ 
   for (int i = threadIdx.x; i < NPAIR * 256; i += blockDim.x) slab[i] = lds[i];
 }
 
+// The same Gram for NT >= 7 tile columns (panels of 112 / 128 columns): 28 / 36 tile pairs of four f64 accumulators each do
+// not fit one wave's registers (the kernel above spills 245 VGPRs at NT = 8 and runs one wave per SIMD: 2.5 ms on C5's
+// 2M x 128 panel, against 0.25 ms of HBM time and 0.5 ms of MFMA time).  Here the four waves of a workgroup stream the
+// SAME 4-row chunks and split the tile pairs among them (pair p belongs to wave p mod 4: nine pairs = 36 accumulator
+// registers each); a chunk is fetched from HBM once and found in L1 by the other three waves.  No LDS, no barrier: every
+// wave writes its own pairs' fragments of the slab.
+template <typename T, int NT, int W>
+__device__ __forceinline__ void gram_split_wave(const T* __restrict__ P, const T* __restrict__ Pb, int64_t rows, int ld, double* __restrict__ slab,
+                                                int lane) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  constexpr int MINE = (NPAIR - W + 3) / 4;   // pairs p = W, W + 4, ...
+  const int g = lane >> 4, c = lane & 15;
+  d4 acc[MINE];
+#pragma unroll
+  for (int p = 0; p < MINE; ++p) acc[p] = d4{0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t r0 = (int64_t)blockIdx.x * 4;
+  constexpr int D = 4;   // chunks in flight
+  T buf[D][NT];
+  auto fetch = [&](int64_t r, int t) -> T {
+    return (r < rows) ? ((Pb && t >= 4) ? Pb[r * ld + 16 * (t - 4) + c] : P[r * ld + 16 * t + c]) : (T)0;
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) buf[d][t] = fetch(r0 + d * stride + g, t);
+  for (; r0 < rows; r0 += D * stride) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = (double)buf[d][t];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) buf[d][t] = fetch(r0 + (d + D) * stride + g, t);
+      int p = 0, mine = 0;
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < NT; ++tb) {
+          if (p % 4 == W) {
+            acc[mine] = mfma_f64(v[ta], v[tb], acc[mine]);
+            ++mine;
+          }
+          ++p;
+        }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MINE; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) slab[((W + 4 * q) * 4 + reg) * WAVE + lane] = acc[q][reg];
+}
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(256)
+gram_split_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restrict__ slabs, const T* __restrict__ Pb) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  const int lane = threadIdx.x & (WAVE - 1);
+  double* slab = slabs + (int64_t)blockIdx.x * NPAIR * 256;
+  switch (threadIdx.x / WAVE) {   // (a wave's pair list is static: its accumulators stay in registers)
+    case 0: gram_split_wave<T, NT, 0>(P, Pb, rows, ld, slab, lane); break;
+    case 1: gram_split_wave<T, NT, 1>(P, Pb, rows, ld, slab, lane); break;
+    case 2: gram_split_wave<T, NT, 2>(P, Pb, rows, ld, slab, lane); break;
+    default: gram_split_wave<T, NT, 3>(P, Pb, rows, ld, slab, lane); break;
+  }
+}
+
 // 16 elements x 16 slab-groups per block; each group sums its slabs in order, the 16 group sums
 // are added in order: a fixed reduction tree, bitwise reproducible.
 __global__ void __launch_bounds__(256)
@@ -554,9 +621,11 @@ template <> struct Quad<double> {
 template <typename T, int NTO>
 __global__ void __launch_bounds__(256)
 panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out, int ldp_stride, int ldm_stride,
-                  int ldo_stride, int accumulate) {
+                  int ldo_stride, int accumulate, int upper) {
   // P: rows x ld at row stride ldp_stride; M: ld x ldo at row stride ldm_stride; out: rows x ldo at row stride ldo_stride
-  // (the wide-panel driver below walks 128-column blocks of a bigger product with these; accumulate: out += P M)
+  // (the wide-panel driver below walks 128-column blocks of a bigger product with these; accumulate: out += P M;
+  //  upper: M is upper triangular -- the normaliser's R^-1 -- and the 16 x 16 blocks below its diagonal are skipped: 10 of
+  //  16 block products at 64 columns, 36 of 64 at 128, where this kernel is bound by the f64 MFMA rate)
   extern __shared__ double Ms[];  // ld x ldo
   for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) Ms[i] = M[(i / ldo) * ldm_stride + (i % ldo)];
   __syncthreads();
@@ -579,7 +648,8 @@ panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M
       for (int e = 0; e < 4; ++e) {
         const double* brow = Ms + (16 * j + 4 * g + e) * ldo + i;
 #pragma unroll
-        for (int tb = 0; tb < NTO; ++tb) acc[tb] = mfma_f64(a4[e], brow[16 * tb], acc[tb]);
+        for (int tb = 0; tb < NTO; ++tb)
+          if (!upper || tb >= j) acc[tb] = mfma_f64(a4[e], brow[16 * tb], acc[tb]);
       }
     }
 #pragma unroll
@@ -902,6 +972,10 @@ inline int grid_for(int64_t work_items, int block, int cap = 4096) {
 template <typename T, int NT>
 void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, hipStream_t s) {
   constexpr int NPAIR = NT * (NT + 1) / 2;
+  if constexpr (NT >= 7) {
+    hipLaunchKernelGGL((gram_split_kernel<T, NT>), dim3(nblocks), dim3(256), 0, s, P, rows, ld, slabs, (const T*)nullptr);
+    return;
+  }
   const size_t lds = (size_t)NPAIR * 256 * sizeof(double);
   static LdsAttrState attr;
   if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_kernel<T, NT>), lds, attr);
@@ -910,7 +984,7 @@ void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, h
 
 template <typename T, int NTO>
 void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, int ldp_stride = 0,
-                       int ldm_stride = 0, int ldo_stride = 0, int accumulate = 0) {
+                       int ldm_stride = 0, int ldo_stride = 0, int accumulate = 0, int upper = 0) {
   const size_t lds = (size_t)ld * ldo * sizeof(double);
   static LdsAttrState attr;
   if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>), lds, attr);
@@ -919,7 +993,7 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((panel_gemm_kernel<T, NTO>), dim3(blocks), dim3(256), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
-                     ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate);
+                     ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
 }
 
 }  // namespace
@@ -948,11 +1022,7 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
     double* G2 = slabs + (size_t)nblocks * npair * 256;
     for (int bi = 0; bi < nb; ++bi)
       for (int bj = bi + 1; bj < nb; ++bj) {
-        constexpr int NPAIR8 = 36;
-        const size_t lds = (size_t)NPAIR8 * 256 * sizeof(double);
-        static LdsAttrState attr;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&gram_kernel<T, 8>), lds, attr);
-        hipLaunchKernelGGL((gram_kernel<T, 8>), dim3(nblocks), dim3(256), lds, s, P + 64 * bi, rows, ld, slabs, P + 64 * bj);
+        hipLaunchKernelGGL((gram_split_kernel<T, 8>), dim3(nblocks), dim3(256), 0, s, P + 64 * bi, rows, ld, slabs, P + 64 * bj);
         hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, 8, 128, G2);
         hipLaunchKernelGGL(gram_place_pair_kernel, dim3(64), dim3(256), 0, s, G2, bi, bj, ld, G);
       }
@@ -1061,8 +1131,9 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
 }
 
 template <typename T, int NTO>
-static void panel_gemm_block(const T* P, int64_t rows, int kd, const double* M, int nd, T* out, hipStream_t s, int ldp, int ldm, int ldo, int acc) {
-  launch_panel_gemm<T, NTO>(P, rows, kd, M, nd, out, s, ldp, ldm, ldo, acc);
+static void panel_gemm_block(const T* P, int64_t rows, int kd, const double* M, int nd, T* out, hipStream_t s, int ldp, int ldm, int ldo, int acc,
+                             int upper) {
+  launch_panel_gemm<T, NTO>(P, rows, kd, M, nd, out, s, ldp, ldm, ldo, acc, upper);
 }
 
 template <typename T>
@@ -1081,19 +1152,20 @@ void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* o
         const int kd = std::min(128, ld - i0);
         if (upper && i0 >= j0 + nd) break;
         const int acc = first ? 0 : 1;
+        const int diag = (upper && i0 == j0) ? 1 : 0;   // (a diagonal block of an upper triangular M is upper triangular itself)
         first = false;
         const T* Pb = P + i0;
         const double* Mb = M + (size_t)i0 * ldo + j0;
         T* ob = out + j0;
         switch (nd / 16) {
-          case 1: panel_gemm_block<T, 1>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          case 2: panel_gemm_block<T, 2>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          case 3: panel_gemm_block<T, 3>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          case 4: panel_gemm_block<T, 4>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          case 5: panel_gemm_block<T, 5>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          case 6: panel_gemm_block<T, 6>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          case 7: panel_gemm_block<T, 7>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
-          default: panel_gemm_block<T, 8>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc); break;
+          case 1: panel_gemm_block<T, 1>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 2: panel_gemm_block<T, 2>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 3: panel_gemm_block<T, 3>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 4: panel_gemm_block<T, 4>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 5: panel_gemm_block<T, 5>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 6: panel_gemm_block<T, 6>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 7: panel_gemm_block<T, 7>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          default: panel_gemm_block<T, 8>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
         }
       }
     }
@@ -1102,14 +1174,14 @@ void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* o
   }
   SAPCA_CHECK(out != P || ldo == ld, SAPCA_ERR_ARG, "panel_gemm: in-place needs ldo == ld");
   switch (ldo / 16) {
-    case 1: launch_panel_gemm<T, 1>(P, rows, ld, M, ldo, out, s); break;
-    case 2: launch_panel_gemm<T, 2>(P, rows, ld, M, ldo, out, s); break;
-    case 3: launch_panel_gemm<T, 3>(P, rows, ld, M, ldo, out, s); break;
-    case 4: launch_panel_gemm<T, 4>(P, rows, ld, M, ldo, out, s); break;
-    case 5: launch_panel_gemm<T, 5>(P, rows, ld, M, ldo, out, s); break;
-    case 6: launch_panel_gemm<T, 6>(P, rows, ld, M, ldo, out, s); break;
-    case 7: launch_panel_gemm<T, 7>(P, rows, ld, M, ldo, out, s); break;
-    default: launch_panel_gemm<T, 8>(P, rows, ld, M, ldo, out, s); break;
+    case 1: launch_panel_gemm<T, 1>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 2: launch_panel_gemm<T, 2>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 3: launch_panel_gemm<T, 3>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 4: launch_panel_gemm<T, 4>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 5: launch_panel_gemm<T, 5>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 6: launch_panel_gemm<T, 6>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 7: launch_panel_gemm<T, 7>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    default: launch_panel_gemm<T, 8>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
   }
   SAPCA_HIP(hipGetLastError());
 }

@@ -657,7 +657,7 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
     double* Rout = pass == 0 ? (R1 ? R1 : Rtmp) : (R2 ? R2 : Rtmp);
     k::chol_inv(G, l, ld, Rout, Rinv, info, s);
     if (ld <= 128) {
-      k::panel_gemm(P, rows, ld, Rinv, ld, P, s);
+      k::panel_gemm(P, rows, ld, Rinv, ld, P, s, true);   // (R^-1 is upper triangular: its zero blocks are skipped)
     } else {   // wide panels: block by block into a second panel, then back (R^-1 is upper triangular)
       T* Q = h.panel_wide.as<T>((size_t)std::max<int64_t>(rows, 1) * ld);
       k::panel_gemm(P, rows, ld, Rinv, ld, Q, s, true);
