@@ -618,14 +618,15 @@ template <> struct Quad<double> {
 
 // out[16-row tile] = P[tile] * M.  Lane (i = lane&15, g = lane>>4) loads the 16-byte segments
 // P[r0+i][16j+4g .. +3]; k-slot g of MFMA step (j, e) is panel column 16j+4g+e on both operands.
-template <typename T, int NTO>
-__global__ void __launch_bounds__(256)
+template <typename T, int NTO, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS)
 panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out, int ldp_stride, int ldm_stride,
                   int ldo_stride, int accumulate, int upper) {
   // P: rows x ld at row stride ldp_stride; M: ld x ldo at row stride ldm_stride; out: rows x ldo at row stride ldo_stride
   // (the wide-panel driver below walks 128-column blocks of a bigger product with these; accumulate: out += P M;
-  //  upper: M is upper triangular -- the normaliser's R^-1 -- and the 16 x 16 blocks below its diagonal are skipped: 10 of
-  //  16 block products at 64 columns, 36 of 64 at 128, where this kernel is bound by the f64 MFMA rate)
+  //  upper > 0: M is (a block column of) an upper triangular matrix -- the normaliser's R^-1 -- whose 16 x 16 blocks below the
+  //  diagonal are skipped: output tile tb stands upper - 1 tiles to the right of K tile 0's diagonal block.  10 of 16
+  //  block products at 64 columns, 36 of 64 at 128, where this kernel is bound by the f64 MFMA rate)
   extern __shared__ double Ms[];  // ld x ldo
   for (int i = threadIdx.x; i < ld * ldo; i += blockDim.x) Ms[i] = M[(i / ldo) * ldm_stride + (i % ldo)];
   __syncthreads();
@@ -634,7 +635,8 @@ panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M
   const int i = lane & 15, g = lane >> 4;
   const int nt = ld / 16;
   const int64_t ntiles = (rows + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  constexpr int WPB = THREADS / WAVE;   // waves (= 16-row tiles in flight) per workgroup
+  for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
     const int64_t r0 = tile * 16;
     const bool row_ok = r0 + i < rows;
     const T* prow = P + (row_ok ? (r0 + i) : 0) * ldp_stride + 4 * g;
@@ -649,7 +651,7 @@ panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M
         const double* brow = Ms + (16 * j + 4 * g + e) * ldo + i;
 #pragma unroll
         for (int tb = 0; tb < NTO; ++tb)
-          if (!upper || tb >= j) acc[tb] = mfma_f64(a4[e], brow[16 * tb], acc[tb]);
+          if (!upper || tb + upper - 1 >= j) acc[tb] = mfma_f64(a4[e], brow[16 * tb], acc[tb]);
       }
     }
 #pragma unroll
@@ -989,6 +991,20 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
   static LdsAttrState attr;
   if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>), lds, attr);
   const int64_t ntiles = (rows + 15) / 16;
+  if constexpr (NTO >= 7) {
+    // M above 80 KiB of LDS leaves one workgroup per CU: twelve waves then instead of four (three per SIMD at 160 VGPRs),
+    // or the kernel sits on one tile's HBM round trip per SIMD at a time (1.7 ms on C5's 2M x 128 panel)
+    if (lds > 80 * 1024) {
+      static LdsAttrState attr12;
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO, 768>), lds, attr12);
+      int blocks = (int)((ntiles + 11) / 12);
+      if (blocks > 256) blocks = 256;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL((panel_gemm_kernel<T, NTO, 768>), dim3(blocks), dim3(768), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
+                         ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
+      return;
+    }
+  }
   int blocks = (int)((ntiles + 3) / 4);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
