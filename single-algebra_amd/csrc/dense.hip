@@ -619,7 +619,7 @@ template <> struct Quad<double> {
 // out[16-row tile] = P[tile] * M.  Lane (i = lane&15, g = lane>>4) loads the 16-byte segments
 // P[r0+i][16j+4g .. +3]; k-slot g of MFMA step (j, e) is panel column 16j+4g+e on both operands.
 template <typename T, int NTO, int THREADS = 256>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1)   // (512 threads: four waves per SIMD, 128 registers)
 panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out, int ldp_stride, int ldm_stride,
                   int ldo_stride, int accumulate, int upper) {
   // P: rows x ld at row stride ldp_stride; M: ld x ldo at row stride ldm_stride; out: rows x ldo at row stride ldo_stride
@@ -1001,6 +1001,19 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
       if (blocks > 256) blocks = 256;
       if (blocks < 1) blocks = 1;
       hipLaunchKernelGGL((panel_gemm_kernel<T, NTO, 768>), dim3(blocks), dim3(768), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
+                         ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
+      return;
+    }
+  }
+  if constexpr (NTO == 4) {
+    // the 64-column panels of the headline configurations: eight waves per workgroup under a 128-register bound (the
+    // 256-thread build takes 228 VGPRs: two waves per SIMD, and the kernel waits on one tile's round trip after another)
+    if (ntiles >= 4096) {
+      static LdsAttrState attr8;
+      if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO, 512>), lds, attr8);
+      int blocks = (int)((ntiles + 7) / 8);
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL((panel_gemm_kernel<T, NTO, 512>), dim3(blocks), dim3(512), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
                          ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
       return;
     }
