@@ -2368,7 +2368,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   std::vector<int32_t> blk_nat;
   float blk_scale = 0.f;
   if (bnd) float_blocks(n, nrb_nat, blk_nat, blk_scale);
-  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 64 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),
+  hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 52 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),   // (above 52 KiB two workgroups share a CU: sixteen waves each)
                      hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, blk_scale, (int)nrb_nat, bnd);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
   launch_small_scan(at_ptr, nullptr, n, nullptr, s);
