@@ -1485,7 +1485,7 @@ constexpr int ATD_HIST_THREADS = 512;   // (a tile per workgroup; eight waves: t
 constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave one workgroup per CU: sixteen waves then (C5: 100 KB)
 
 // With `bnd` (the gather fill below, natural row order of A^T): A^T's row blocks are contiguous column ranges -- block b
-// holds the columns c with (int)((float)c * blk_scale) == b -- and bnd[b][t * tc + i] becomes the position in A's arrays of the first entry of row
+// holds the columns c with (int)((float)c * blk_scale) == b -- and bnd[t * tc + i][b] becomes the position in A's arrays of the first entry of row
 // t + i * nct whose column lies in block b or behind (b = 0..nrb; the row's end for the blocks it does not reach).  A row is
 // sorted by column, so these are the places where the block of the column changes: found in the registers that hold the
 // row's indices for the histogram anyway.
@@ -1499,7 +1499,6 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
   for (int i = threadIdx.x; i < nw; i += nthreads) atd_h32[i] = 0u;
   __syncthreads();
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  const int64_t bstride = (int64_t)nct * tc;
   // (the next row's offsets are fetched while this row's indices are in flight: a row is one batch at C5's 500 entries)
   int64_t r = (int64_t)t + (int64_t)wave * nct;
   int64_t e0 = (wave < tc && r < m) ? ptr[r] : 0, e1 = (wave < tc && r < m) ? ptr[r + 1] : 0;
@@ -1509,7 +1508,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
     const bool more = i + nwaves < tc && rn < m;
     const int64_t n0 = more ? ptr[rn] : 0, n1 = more ? ptr[rn + 1] : 0;
     int lastb = -1;   // block of the last entry seen in this row (wave-uniform)
-    int64_t* __restrict__ bnd_row = bnd ? bnd + (int64_t)t * tc + i : nullptr;
+    int64_t* __restrict__ bnd_row = bnd ? bnd + ((int64_t)t * tc + i) * (nrb + 1) : nullptr;   // a row's run ends side by side
     for (int64_t base = e0; base < e1; base += 8 * WAVE) {   // eight loads in flight per lane (a wave-uniform trip count: the
       const int64_t eb = base + lane;                         //  boundary search below talks across lanes)
       int c[8];
@@ -1527,7 +1526,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
           const int up = __builtin_amdgcn_update_dpp(0, b, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane l reads lane l - 1
           const int prev = lane == 0 ? lastb : up;
           if (valid && b != prev)
-            for (int j = prev + 1; j <= b; ++j) bnd_row[(int64_t)__umul24((uint32_t)j, (uint32_t)bstride)] = eb + u * WAVE;   // (rows of A < 2^24)
+            for (int j = prev + 1; j <= b; ++j) bnd_row[j] = eb + u * WAVE;
           lastb = __builtin_amdgcn_readlane(b, __builtin_popcountll(valids) - 1);
         }
       }
@@ -1536,7 +1535,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
         if (c[u] >= 0) atomicAdd(&atd_h32[c[u] >> 1], 1u << (16 * (c[u] & 1)));   // (at most 320 rows per tile: no carry into the neighbour)
     }
     if (bnd)
-      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd_row[(int64_t)j * bstride] = e1;
+      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd_row[j] = e1;
     r = rn;
     e0 = n0;
     e1 = n1;
@@ -1704,9 +1703,10 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
   if constexpr (GATHER) {
     if (threadIdx.x < 32 * ATD_MASK_WORDS) {   // (the same first waves; tc <= 320)
       const int i = threadIdx.x, lane = i & (WAVE - 1);
-      const int64_t bstride = (int64_t)nct * tc;
-      const int64_t lo = i < tc ? bnd[(int64_t)rb * bstride + (int64_t)t * tc + i] : 0;
-      const int64_t hi = i < tc ? bnd[(int64_t)(rb + 1) * bstride + (int64_t)t * tc + i] : 0;
+      // (bnd[row][block]: the chunks of one tile, run back to back on this XCD, read neighbouring words of the same lines)
+      const int64_t* br = bnd + ((int64_t)t * tc + i) * (nrb_all + 1) + rb;
+      const int64_t lo = i < tc ? br[0] : 0;
+      const int64_t hi = i < tc ? br[1] : 0;
       run_lo[i] = lo;
       uint32_t inc = hi > lo ? (uint32_t)(hi - lo) : 0u;
 #pragma unroll
@@ -2357,7 +2357,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   int nsplit_nat = 1;
   natural_partition(n, nct, dq_block_rows(n), nrb_nat, nsplit_nat);
   int64_t* bnd = nullptr;
-  if (getenv("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096 && (int64_t)nct * tc < (1 << 24)) {   // (24-bit products in the histogram pass)
+  if (getenv("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096) {
     const size_t bytes = (size_t)(nrb_nat + 1) * (size_t)nct * tc * sizeof(int64_t);
     bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
     SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
