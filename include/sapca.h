@@ -38,8 +38,10 @@
 extern "C" {
 #endif
 
-#define SAPCA_ABI_VERSION 3   /* 2: sapca_timings grew sweep_kernel / sweep_slots_*; sapca_comm_rccl_available
-                                 3: sapca_multi_* (one handle, several GPUs), sapca_upload_values_changed */
+#define SAPCA_ABI_VERSION 4   /* 2: sapca_timings grew sweep_kernel / sweep_slots_*; sapca_comm_rccl_available
+                                 3: sapca_multi_* (one handle, several GPUs), sapca_upload_values_changed
+                                 4: *_csr_device_to_host_*, sapca_comm_abort / _async_error / _has_side_lane,
+                                    sapca_multi_upload_csr_* and the sapca_multi_*_resident calls        */
 
 typedef struct sapca_handle_s* sapca_handle;
 
@@ -177,6 +179,17 @@ sapca_status sapca_fit_transform_csr_device_f32(sapca_handle h, uint64_t m, uint
                                                 const int64_t* d_row_offsets, const int32_t* d_col_indices, const float* d_values, float* d_out);
 sapca_status sapca_fit_transform_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
                                                 const int64_t* d_row_offsets, const int32_t* d_col_indices, const double* d_values, double* d_out);
+/* The same two calls with the m x n_components projection delivered to HOST memory (through the
+ * handle's page-locked ring): what a caller whose matrix is resident (sapca_upload_csr_*) but whose
+ * consumer is host code -- the reference's Array2<T> result, sparse/mod.rs:255-285 -- wants.     */
+sapca_status sapca_transform_csr_device_to_host_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                                    const int64_t* d_row_offsets, const int32_t* d_col_indices, const float* d_values, float* out);
+sapca_status sapca_transform_csr_device_to_host_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                                    const int64_t* d_row_offsets, const int32_t* d_col_indices, const double* d_values, double* out);
+sapca_status sapca_fit_transform_csr_device_to_host_f32(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                                        const int64_t* d_row_offsets, const int32_t* d_col_indices, const float* d_values, float* out);
+sapca_status sapca_fit_transform_csr_device_to_host_f64(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,
+                                                        const int64_t* d_row_offsets, const int32_t* d_col_indices, const double* d_values, double* out);
 
 /* Fitted state.  The reference keeps components_/explained_variance_/mean_ private
  * (sparse/mod.rs:41-43); a Rust wrapper needs them to populate those fields.
@@ -308,6 +321,22 @@ typedef int (*sapca_allreduce_fn)(void* ctx, void* buf, uint64_t count, int32_t 
 sapca_status sapca_comm_set_callback(sapca_handle h, uint32_t nranks, uint32_t rank, sapca_allreduce_fn fn, void* ctx);
 /* Invokes the handle's collective once on a caller buffer (plumbing self-test).               */
 sapca_status sapca_comm_allreduce(sapca_handle h, void* buf, uint64_t count, int32_t dtype);
+/* A rank that fails OUTSIDE a collective (out of memory, a HIP error, a refused argument) never
+ * joins the collectives its peers are waiting in.  Under the built-in RCCL transport the way out
+ * is ncclCommAbort: sapca_comm_abort ends every collective of THIS handle that is in flight or
+ * still to come -- a fit blocked behind one returns SAPCA_ERR_COMM -- and may be called from any
+ * thread while a fit of the handle is running.  sapca_multi_* does this for its members; in the
+ * one-process-per-GPU deployment the HOST program must: when a rank's call fails, tell the peers
+ * (its own control channel) and have each call sapca_comm_abort on its handle, or poll
+ * sapca_comm_async_error (0 = healthy; otherwise RCCL's ncclResult_t, -1 after an abort) from a
+ * watchdog thread.  The communicator is gone afterwards: sapca_comm_init_rank again.            */
+sapca_status sapca_comm_abort(sapca_handle h);
+sapca_status sapca_comm_async_error(sapca_handle h, int32_t* state);
+/* 1 when collectives issued on the library's side stream have a lane of their own (a callback
+ * transport, or RCCL with the duplicate communicator made by ncclCommSplit at init): the A^T
+ * sweep of a row-sharded fit then runs in two pieces with the first piece's all-reduce behind
+ * the second piece's sweep.  Every rank must see the same answer.                               */
+int sapca_comm_has_side_lane(sapca_handle h);
 
 
 /* ---- one handle, several GPUs, one calling thread (SURVEY.md §8b "Threading", §8e) ----------
@@ -318,6 +347,10 @@ sapca_status sapca_comm_allreduce(sapca_handle h, void* buf, uint64_t count, int
  * blocks until all are done.  The members are the ranks of one communicator: RCCL between
  * distinct devices, an in-process all-reduce through page-locked host memory when a device is
  * listed more than once (a one-GPU box rehearsing the path) or librccl does not resolve.
+ * A member that fails (out of memory, a refused shard, a HIP error) ends the call for all: the
+ * peers' collectives are abandoned (in-process) or aborted (ncclCommAbort on every member's
+ * communicators), every member returns, the call reports the first failure, and the next call
+ * builds new communicators -- no call blocks on a peer that has left.
  * `out` (m x n_components, row-major, HOST) receives every shard's rows in place.  The fitted
  * state is replicated and bitwise identical on all members: read it from any member with the
  * sapca_get_* functions (sapca_multi_member(mh, 0)); sapca_set_omega_* must be applied to every
@@ -343,6 +376,27 @@ sapca_status sapca_multi_fit_transform_csr_f32(sapca_multi mh, uint64_t m, uint6
                                                const uint64_t* row_offsets, const uint64_t* col_indices, const float* values, float* out);
 sapca_status sapca_multi_fit_transform_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
                                                const uint64_t* row_offsets, const uint64_t* col_indices, const double* values, double* out);
+/* Resident shards (SURVEY.md §8f-1 for several devices): sapca_multi_upload_csr_* partitions the HOST
+ * CsrMatrix as above and uploads every shard to its device ONCE (the uploads run side by side, one
+ * host thread per device); the *_resident calls then fit / project the uploaded shards without
+ * touching PCIe for the matrix again -- repeated fits (another k, another mask, another seed)
+ * skip the upload, which is where the wall-clock of a one-off call goes (10.8 GB of usize CSR at
+ * BASELINE configs[3]).  `out` is HOST memory, m x n_components, as above.  The shards stay valid
+ * until the next sapca_multi_upload_csr_* / non-resident call on this sapca_multi.
+ * sapca_multi_resident_shard: the row range and the device arrays of member i's shard (for
+ * callers that preprocess in HBM with sapca_normalize_csr_device_* / sapca_log1p_csr_device_* on
+ * sapca_multi_member(mh, i)); any output may be NULL.                                           */
+sapca_status sapca_multi_upload_csr_f32(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                        const uint64_t* row_offsets, const uint64_t* col_indices, const float* values);
+sapca_status sapca_multi_upload_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz,
+                                        const uint64_t* row_offsets, const uint64_t* col_indices, const double* values);
+sapca_status sapca_multi_fit_resident(sapca_multi mh);
+sapca_status sapca_multi_transform_resident_f32(sapca_multi mh, float* out);
+sapca_status sapca_multi_transform_resident_f64(sapca_multi mh, double* out);
+sapca_status sapca_multi_fit_transform_resident_f32(sapca_multi mh, float* out);
+sapca_status sapca_multi_fit_transform_resident_f64(sapca_multi mh, double* out);
+sapca_status sapca_multi_resident_shard(sapca_multi mh, uint32_t i, uint64_t* first_row, uint64_t* rows, uint64_t* nnz,
+                                        const int64_t** d_row_offsets, const int32_t** d_col_indices, void** d_values);
 
 #ifdef __cplusplus
 }

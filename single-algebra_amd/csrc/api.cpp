@@ -282,10 +282,12 @@ sapca_status fit_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, co
 
 template <typename T>
 sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const int64_t* p,
-                              const int32_t* i, const T* v, T* d_out, bool fit_first) {
+                              const int32_t* i, const T* v, T* d_out, bool fit_first, bool out_on_host = false) {
   return guarded(h, [&] {
     SAPCA_CHECK(d_out != nullptr || m == 0, SAPCA_ERR_ARG, "null output buffer");
     CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
+    T* host_out = out_on_host ? d_out : nullptr;
+    if (out_on_host) d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * h->opt.n_components, 1));
     if (fit_first) {
       Engine<T>::fit(*h, A, true);
     } else if (static_cast<const void*>(v) != h->in_val.p) {
@@ -298,6 +300,7 @@ sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t n
     }
     try {
       Engine<T>::transform(*h, A, d_out);
+      if (host_out) download_out(h, d_out, host_out, (size_t)(m * h->k));
     } catch (...) {
       Engine<T>::finish_fit(*h);   // (a fit whose tail was held back for the projection still completes)
       throw;
@@ -639,6 +642,7 @@ void sapca_destroy(sapca_handle h) {
     (void)hipStreamSynchronize(h->stream3);
     (void)hipStreamDestroy(h->stream3);
   }
+  if (h->ev_small) (void)hipEventDestroy(h->ev_small);
   if (h->ev_kept) (void)hipEventDestroy(h->ev_kept);
   if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -700,6 +704,14 @@ sapca_status sapca_set_omega_f64(sapca_handle h, const double* omega, size_t row
   sapca_status sapca_fit_transform_csr_device_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,                \
                                                     const int64_t* p, const int32_t* i, const T* v, T* out) {            \
     return transform_device<T>(h, m, n, nnz, p, i, v, out, true);                                                        \
+  }                                                                                                                      \
+  sapca_status sapca_transform_csr_device_to_host_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,            \
+                                                        const int64_t* p, const int32_t* i, const T* v, T* out) {        \
+    return transform_device<T>(h, m, n, nnz, p, i, v, out, false, true);                                                 \
+  }                                                                                                                      \
+  sapca_status sapca_fit_transform_csr_device_to_host_##SUF(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz,        \
+                                                            const int64_t* p, const int32_t* i, const T* v, T* out) {    \
+    return transform_device<T>(h, m, n, nnz, p, i, v, out, true, true);                                                  \
   }                                                                                                                      \
   sapca_status sapca_get_components_##SUF(sapca_handle h, T* out, size_t cap) {                                          \
     return guarded(h, [&] { get_components<T>(h, out, cap, false); });                                                   \
@@ -855,6 +867,28 @@ sapca_status sapca_comm_init_rank(sapca_handle h, uint32_t nranks, uint32_t rank
 sapca_status sapca_comm_set_callback(sapca_handle h, uint32_t nranks, uint32_t rank, sapca_allreduce_fn fn, void* ctx) {
   return guarded(h, [&] { h->comm.set_callback(nranks, rank, fn, ctx); });
 }
+
+sapca_status sapca_comm_abort(sapca_handle h) {
+  if (!h) return SAPCA_ERR_ARG;
+  try {   // (not `guarded`: callable from another thread while a fit of this handle is blocked behind a collective)
+    h->comm.abort();
+    return SAPCA_OK;
+  } catch (...) {
+    return SAPCA_ERR_COMM;
+  }
+}
+
+sapca_status sapca_comm_async_error(sapca_handle h, int32_t* state) {
+  if (!h || !state) return SAPCA_ERR_ARG;
+  try {
+    *state = h->comm.async_error();
+    return SAPCA_OK;
+  } catch (...) {
+    return SAPCA_ERR_COMM;
+  }
+}
+
+int sapca_comm_has_side_lane(sapca_handle h) { return (h && h->comm.has_side_lane()) ? 1 : 0; }
 
 sapca_status sapca_comm_allreduce(sapca_handle h, void* buf, uint64_t count, int32_t dtype) {
   return guarded(h, [&] {

@@ -19,6 +19,9 @@ struct RcclApi {
   int (*CommInitRank)(ncclComm_t*, int, RcclId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;
+  int (*CommGetAsyncError)(ncclComm_t, int*) = nullptr;
+  int (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   void* so = nullptr;
 };
@@ -38,6 +41,9 @@ RcclApi& api() {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.so, "ncclCommInitRank"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.so, "ncclAllReduce"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.so, "ncclCommDestroy"));
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.so, "ncclCommAbort"));
+    a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(dlsym(a.so, "ncclCommGetAsyncError"));
+    a.CommSplit = reinterpret_cast<decltype(a.CommSplit)>(dlsym(a.so, "ncclCommSplit"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.so, "ncclGetErrorString"));
   });
   if (!a.so || !a.GetUniqueId || !a.CommInitRank || !a.AllReduce)
@@ -83,6 +89,13 @@ void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
   check(api().CommInitRank(&c, (int)nranks, u, (int)rank), "ncclCommInitRank");
   rccl_comm = c;
   mode = RCCL;
+  aborted.store(false);
+  // the side stream's communicator: a collective split with one colour (every rank enters it right behind the init)
+  rccl_comm2 = nullptr;
+  if (api().CommSplit && getenv("SAPCA_COMM_NO_SPLIT") == nullptr) {
+    ncclComm_t c2 = nullptr;
+    if (api().CommSplit(c, 0, (int)rank, &c2, nullptr) == 0) rccl_comm2 = c2;
+  }
 }
 
 void Comm::set_callback(uint32_t nranks_, uint32_t rank_, sapca_allreduce_fn f, void* c) {
@@ -96,11 +109,13 @@ void Comm::set_callback(uint32_t nranks_, uint32_t rank_, sapca_allreduce_fn f, 
   mode = nranks > 1 ? CALLBACK : NONE;
 }
 
-void Comm::allreduce(void* buf, uint64_t count, int dtype, hipStream_t s) {
+void Comm::allreduce(void* buf, uint64_t count, int dtype, hipStream_t s, int lane) {
   if (!active() || count == 0) return;
+  if (aborted.load()) throw Error(SAPCA_ERR_COMM, "communicator aborted: a peer of this fit failed");
   auto t0 = std::chrono::steady_clock::now();
   if (mode == RCCL) {
-    check(api().AllReduce(buf, buf, (size_t)count, dtype == 1 ? kNcclFloat64 : kNcclFloat32, kNcclSum, rccl_comm, s),
+    SAPCA_CHECK(lane == 0 || rccl_comm2 != nullptr, SAPCA_ERR_COMM, "internal: no communicator for the side stream");
+    check(api().AllReduce(buf, buf, (size_t)count, dtype == 1 ? kNcclFloat64 : kNcclFloat32, kNcclSum, lane == 0 ? rccl_comm : rccl_comm2, s),
           "ncclAllReduce");
   } else if (mode == CALLBACK) {
     if (fn(ctx, buf, count, dtype, (void*)s) != 0) throw Error(SAPCA_ERR_COMM, "all-reduce callback reported failure");
@@ -110,8 +125,32 @@ void Comm::allreduce(void* buf, uint64_t count, int dtype, hipStream_t s) {
   host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+void Comm::abort() {
+  if (aborted.exchange(true)) return;
+  if (mode != RCCL || !api().CommAbort) return;
+  // (ncclCommAbort frees the communicator: destroy() must not touch it again)
+  void* c2 = rccl_comm2;
+  void* c1 = rccl_comm;
+  rccl_comm2 = nullptr;
+  rccl_comm = nullptr;
+  if (c2) (void)api().CommAbort(c2);
+  if (c1) (void)api().CommAbort(c1);
+}
+
+int Comm::async_error() {
+  if (aborted.load()) return -1;
+  if (mode != RCCL || !api().CommGetAsyncError) return 0;
+  int e = 0;
+  if (rccl_comm && api().CommGetAsyncError(rccl_comm, &e) == 0 && e != 0) return e;
+  if (rccl_comm2 && api().CommGetAsyncError(rccl_comm2, &e) == 0 && e != 0) return e;
+  return 0;
+}
+
 void Comm::destroy() {
+  if (mode == RCCL && rccl_comm2 && api().CommDestroy) (void)api().CommDestroy(rccl_comm2);
   if (mode == RCCL && rccl_comm && api().CommDestroy) (void)api().CommDestroy(rccl_comm);
+  rccl_comm2 = nullptr;
+  aborted.store(false);
   rccl_comm = nullptr;
   fn = nullptr;
   ctx = nullptr;

@@ -155,28 +155,259 @@ gram_split_kernel(const T* __restrict__ P, int64_t rows, int ld, double* __restr
   }
 }
 
+
+// ---------------------------------------------------------------- Gram with the producer's fix-up folded into its read pass
+// Panels of 64 / 128 columns (NT = 4 / 8: every headline configuration).  A lane reads 16 bytes: lane (g, c) of a 4-row chunk
+// holds columns 4c .. 4c+3 (and 64 + 4c .. for the second half) of row g, so MFMA tile t is the column set
+// vcol(t, i) = 64 (t >> 2) + 4 i + (t & 3) -- a fixed permutation of the panel's columns that gram_reduce_kernel undoes.
+// SRC: the panel is still in the state its producer left it in (PanelSource: the slabs of a sweep whose tile range was split
+// over workgroups, minus the centring term mu sv^T).  Every element passes through exactly one lane here: it is summed,
+// centred, written back to P and used -- split_reduce, rank1_subtract and one read of the panel are gone.
+// want_sum: sum_r w[r] P[r][:] (w null: ones) rides along in f64 (the centring vector of the next sweep follows from it and
+// R^-1: chol_inv).  NT = 8: the four waves stream the same rows and split the 36 tile pairs (see gram_split_kernel); wave 0
+// does the write-back and the column sums.
+__device__ __forceinline__ int vcol(int t, int i) { return 64 * (t >> 2) + 4 * i + (t & 3); }
+
+template <typename T> struct Four;
+template <> struct Four<float> {
+  __device__ static inline void load(const float* p, float out[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+  __device__ static inline void store(float* p, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Four<double> {
+  __device__ static inline void load(const double* p, double out[4]) {
+    const double2 a = *reinterpret_cast<const double2*>(p);
+    const double2 b = *reinterpret_cast<const double2*>(p + 2);
+    out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+  }
+  __device__ static inline void store(double* p, const double v[4]) {
+    *reinterpret_cast<double2*>(p) = make_double2(v[0], v[1]);
+    *reinterpret_cast<double2*>(p + 2) = make_double2(v[2], v[3]);
+  }
+};
+
+template <typename T, int NT, bool SRC, int W>
+__device__ __forceinline__ void gramv_wave(T* P, int64_t rows, int ld, double* __restrict__ slab, double* lds,
+                                           const PanelSource<T>& src, const T* __restrict__ wgt, int want_sum, int lane, int wave) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  constexpr bool SPLIT = NT > 6;
+  constexpr int MINE = SPLIT ? (NPAIR - W + 3) / 4 : NPAIR;
+  constexpr int NH = NT / 4;
+  const int g = lane >> 4, c = lane & 15;
+  const bool owner = !SPLIT || W == 0;   // writes the panel back, sums the columns
+  d4 acc[MINE];
+#pragma unroll
+  for (int p = 0; p < MINE; ++p) acc[p] = d4{0, 0, 0, 0};
+  double cs[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cs[t] = 0;
+  const int64_t stride = SPLIT ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x * 16;
+  int64_t r0 = SPLIT ? (int64_t)blockIdx.x * 4 : ((int64_t)blockIdx.x * 4 + wave) * 4;
+  auto mma = [&](const T (&x)[NT], double wr) {
+    double v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] = (double)x[t];
+    if (want_sum && owner) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cs[t] += wr * v[t];
+    }
+    int p = 0, mine = 0;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb) {
+        if (!SPLIT || p % 4 == W) {
+          acc[mine] = mfma_f64(v[ta], v[tb], acc[mine]);
+          ++mine;
+        }
+        ++p;
+      }
+  };
+  if constexpr (SRC) {
+    T sv[NT];
+    if (src.mu) {
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) Four<T>::load(src.sv + 64 * hh + 4 * c, &sv[4 * hh]);
+    }
+    for (; r0 < rows; r0 += stride) {
+      const int64_t r = r0 + g;
+      T x[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) x[t] = (T)0;
+      double wr = 0;
+      if (r < rows) {
+        const T* p = src.parts + r * ld + 4 * c;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) Four<T>::load(p + 64 * hh, &x[4 * hh]);
+        for (int sp = 1; sp < src.nsplit; ++sp) {
+          T y[NT];
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh) Four<T>::load(p + sp * src.slab_stride + 64 * hh, &y[4 * hh]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) x[t] += y[t];
+        }
+        if (src.mu) {
+          const T m = src.mu[r];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) x[t] -= m * sv[t];
+        }
+        if (owner) {
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh) Four<T>::store(P + r * ld + 64 * hh + 4 * c, &x[4 * hh]);
+        }
+        wr = wgt ? (double)wgt[r] : 1.0;
+      }
+      mma(x, wr);
+    }
+  } else {
+    constexpr int D = NT == 4 ? 4 : 2;   // chunks in flight
+    T buf[D][NT];
+    double wb[D];
+    auto fetch = [&](int64_t r, T (&out)[NT], double& wr) {
+      if (r < rows) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) Four<T>::load(P + r * ld + 64 * hh + 4 * c, &out[4 * hh]);
+        wr = (want_sum && wgt) ? (double)wgt[r] : 1.0;
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) out[t] = (T)0;
+        wr = 0;
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(r0 + d * stride + g, buf[d], wb[d]);
+    for (; r0 < rows; r0 += D * stride) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        T x[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = buf[d][t];
+        const double wr = wb[d];
+        fetch(r0 + (d + D) * stride + g, buf[d], wb[d]);
+        mma(x, wr);
+      }
+    }
+  }
+  // column sums: over the four row groups of the wave by shuffles; over the waves in order through LDS
+  if (want_sum && owner) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      cs[t] += __shfl_xor(cs[t], 16);
+      cs[t] += __shfl_xor(cs[t], 32);
+    }
+  }
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int q = 0; q < MINE; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) slab[((W + 4 * q) * 4 + reg) * WAVE + lane] = acc[q][reg];
+    if (owner && g == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) slab[NPAIR * 256 + 16 * t + c] = want_sum ? cs[t] : 0.0;
+    }
+  } else {
+    double* lsum = lds + NPAIR * 256;   // [wave][16 NT]
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            double* dst = lds + (p * 4 + reg) * WAVE + lane;
+            if (w == 0) *dst = acc[p][reg]; else *dst += acc[p][reg];
+          }
+        if (g == 0) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            double* dst = lsum + 16 * t + c;
+            if (w == 0) *dst = cs[t]; else *dst += cs[t];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NPAIR * 256 + 16 * NT; i += blockDim.x) slab[i] = lds[i];
+  }
+}
+
+template <typename T, int NT, bool SRC>
+__global__ void __launch_bounds__(256)
+gramv_kernel(T* P, int64_t rows, int ld, double* __restrict__ slabs, PanelSource<T> src, const T* __restrict__ wgt, int want_sum) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  extern __shared__ double lds[];   // NT <= 6: NPAIR * 256 + 16 NT doubles
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  double* slab = slabs + (int64_t)blockIdx.x * (NPAIR * 256 + 16 * NT);
+  if constexpr (NT > 6) {
+    switch (wave) {   // (a wave's pair list is static: its accumulators stay in registers)
+      case 0: gramv_wave<T, NT, SRC, 0>(P, rows, ld, slab, lds, src, wgt, want_sum, lane, wave); break;
+      case 1: gramv_wave<T, NT, SRC, 1>(P, rows, ld, slab, lds, src, wgt, want_sum, lane, wave); break;
+      case 2: gramv_wave<T, NT, SRC, 2>(P, rows, ld, slab, lds, src, wgt, want_sum, lane, wave); break;
+      default: gramv_wave<T, NT, SRC, 3>(P, rows, ld, slab, lds, src, wgt, want_sum, lane, wave); break;
+    }
+  } else {
+    gramv_wave<T, NT, SRC, 0>(P, rows, ld, slab, lds, src, wgt, want_sum, lane, wave);
+  }
+}
+
+// P = sum_s parts[s] - mu sv^T, written out: the same fix-up for panels the kernel above does not take
+template <typename T>
+__global__ void materialize_kernel(T* P, int64_t rows, int ld, PanelSource<T> src) {
+  const int64_t total = rows * ld;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    T x = src.parts[i];
+    for (int sp = 1; sp < src.nsplit; ++sp) x += src.parts[(int64_t)sp * src.slab_stride + i];
+    if (src.mu) x -= src.mu[i / ld] * src.sv[i % ld];
+    P[i] = x;
+  }
+}
+
+// vec[j] = sum_{i <= j} Rinv[i][j] wsum[i]: the column sums of P R^-1 from those of P (the normaliser's output is never re-read)
+template <typename T>
+__global__ void rinv_tvec_kernel(const double* __restrict__ Rinv, int l, int ld, const double* __restrict__ wsum, T* __restrict__ vec) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ld) return;
+  double s = 0;
+  if (j < l)
+    for (int i = 0; i <= j; ++i) s += Rinv[(size_t)i * ld + j] * wsum[i];
+  vec[j] = (T)s;
+}
+
 // 16 elements x 16 slab-groups per block; each group sums its slabs in order, the 16 group sums
 // are added in order: a fixed reduction tree, bitwise reproducible.
 __global__ void __launch_bounds__(256)
-gram_reduce_kernel(const double* __restrict__ slabs, int nslabs, int nt, int ld, double* __restrict__ G) {
+gram_reduce_kernel(const double* __restrict__ slabs, int nslabs, int nt, int ld, double* __restrict__ G, int vtiles = 0,
+                   double* __restrict__ wsum = nullptr) {
+  // vtiles: the slabs come from gramv_kernel -- tile t is the column set vcol(t, .), and 16 nt (weighted) column sums
+  // follow the fragments of every slab (wsum, nullable, receives their total)
   __shared__ double part[16][17];
   const int npair = nt * (nt + 1) / 2;
+  const int slab_len = npair * 256 + (vtiles ? 16 * nt : 0);
   const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + e;
   double sum = 0;
-  if (i < npair * 256)
-    for (int b = grp; b < nslabs; b += 16) sum += slabs[(int64_t)b * npair * 256 + i];
+  if (i < slab_len)
+    for (int b = grp; b < nslabs; b += 16) sum += slabs[(int64_t)b * slab_len + i];
   part[grp][e] = sum;
   __syncthreads();
-  if (grp != 0 || i >= npair * 256) return;
+  if (grp != 0 || i >= slab_len) return;
   sum = 0;
 #pragma unroll
   for (int g2 = 0; g2 < 16; ++g2) sum += part[g2][e];
+  if (i >= npair * 256) {
+    const int t = (i - npair * 256) / 16, c = (i - npair * 256) % 16;
+    if (wsum) wsum[vcol(t, c)] = sum;
+    return;
+  }
   int p = i / 256, rem = i % 256, reg = rem / 64, lane = rem % 64;
   int ta = 0;
   while (p >= nt - ta) { p -= nt - ta; ++ta; }
   const int tb = ta + p;
-  const int row = 16 * ta + (lane >> 4) + 4 * reg, col = 16 * tb + (lane & 15);
+  const int row = vtiles ? vcol(ta, (lane >> 4) + 4 * reg) : 16 * ta + (lane >> 4) + 4 * reg;
+  const int col = vtiles ? vcol(tb, lane & 15) : 16 * tb + (lane & 15);
   G[row * ld + col] = sum;
   G[col * ld + row] = sum;
 }
@@ -306,7 +537,7 @@ __device__ __forceinline__ d4 block_mma(const double* pa, int sai, int sak, cons
 }
 
 constexpr int CHB = 16, CHN = 64, CHP = 65;
-constexpr int kCholBlockedLds = (2 * CHN * CHP + CHN) * (int)sizeof(double);
+constexpr int kCholBlockedLds = (2 * CHN * CHP + 2 * CHN) * (int)sizeof(double);
 #ifdef SAPCA_CHOL_TIMING   // tools/ubench/chol_phases.hip: shader-clock stamps at the phase boundaries
 __device__ unsigned long long sapca_chol_stamps[32];
 #define CHOL_STAMP(k) if (threadIdx.x == 0) sapca_chol_stamps[k] = __builtin_readcyclecounter();
@@ -419,11 +650,13 @@ __device__ __forceinline__ void chol_inv_core(double* Lm, double* Xm, double* di
 
 __global__ void __launch_bounds__(256)
 chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __restrict__ R, double* __restrict__ Rinv,
-                        int* __restrict__ info) {
+                        int* __restrict__ info, const double* __restrict__ wsum, float* __restrict__ vec32, double* __restrict__ vec64) {
   extern __shared__ double cb_lds[];
   double* Lm = cb_lds;              // Lm[i * CHP + c] = L[i][c] (lower), in place over G
   double* Xm = Lm + CHN * CHP;      // Xm[i * CHP + c] = (L^-1)[i][c]
   double* dinvs = Xm + CHN * CHP;
+  double* ws = dinvs + CHN;         // the (weighted) column sums of the panel being normalised
+  if (wsum && threadIdx.x < CHN) ws[threadIdx.x] = (int)threadIdx.x < l ? wsum[threadIdx.x] : 0.0;
   const int t = threadIdx.x, lane = t & 63;
   const int nb = (l + CHB - 1) / CHB;
   CHOL_STAMP(0)
@@ -467,6 +700,15 @@ chol_inv_blocked_kernel(const double* __restrict__ G, int l, int ld, double* __r
     }
   }
   CHOL_STAMP(14)
+  if (wsum && t < ld) {
+    // vec[j] = sum_{i <= j} Rinv[i][j] ws[i] = row j of L^-1 times ws: the column sums of P R^-1 (the centring vector of
+    // the next sweep) without another pass over the normalised panel
+    double acc = 0;
+    if (t < l)
+      for (int i2 = 0; i2 <= t; ++i2) acc += Xm[t * CHP + i2] * ws[i2];
+    if (vec32) vec32[t] = (float)acc;
+    if (vec64) vec64[t] = acc;
+  }
   if (t == 0 && bad) atomicAdd(info, bad);
 }
 
@@ -621,8 +863,9 @@ template <> struct Quad<double> {
 template <typename T, int NTO, int THREADS = 256>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1)   // (512 threads: four waves per SIMD, 128 registers)
 panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M, int ldo, T* out, int ldp_stride, int ldm_stride,
-                  int ldo_stride, int accumulate, int upper) {
+                  int ldo_stride, int accumulate, int upper, int ncols_out) {
   // P: rows x ld at row stride ldp_stride; M: ld x ldo at row stride ldm_stride; out: rows x ldo at row stride ldo_stride
+  // (only the first ncols_out columns are written: the projection's m x k output has row stride k, not a multiple of 16)
   // (the wide-panel driver below walks 128-column blocks of a bigger product with these; accumulate: out += P M;
   //  upper > 0: M is (a block column of) an upper triangular matrix -- the normaliser's R^-1 -- whose 16 x 16 blocks below the
   //  diagonal are skipped: output tile tb stands upper - 1 tiles to the right of K tile 0's diagonal block.  10 of 16
@@ -659,7 +902,7 @@ panel_gemm_kernel(const T* P, int64_t rows, int ld, const double* __restrict__ M
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = r0 + g + 4 * reg;
-        if (r < rows) {
+        if (r < rows && 16 * tb + i < ncols_out) {
           T* o = out + r * ldo_stride + 16 * tb + i;
           *o = accumulate ? (T)((double)*o + acc[tb][reg]) : (T)acc[tb][reg];
         }
@@ -938,6 +1181,23 @@ __global__ void scaled_transpose_kernel(const T* __restrict__ comps, int64_t n, 
   }
 }
 
+// out[j][c] = scale[j] * P[j][c]  (scale null: a plain copy) -- the un-rotated projection panel diag(cnt) B^T of fit_transform
+template <typename T>
+__global__ void scale_rows_kernel(const T* __restrict__ P, int64_t rows, int ld, const double* __restrict__ scale, T* __restrict__ out) {
+  const int64_t total = rows * ld;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) out[i] = scale ? (T)(scale[i / ld] * (double)P[i]) : P[i];
+}
+
+// M[i][j] *= sign[j]  (j < k): the svd_flip signs carried into the factor the deferred projection is rotated with
+__global__ void scale_columns_kernel(double* __restrict__ M, int rows, int ld, int k, const double* __restrict__ sign) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld) return;
+  const int j = i % ld;
+  if (j < k) M[i] *= sign[j];
+}
+
 template <typename T>
 __global__ void fill_zero_kernel(T* p, int64_t count) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -971,6 +1231,18 @@ inline int grid_for(int64_t work_items, int block, int cap = 4096) {
   return (int)g;
 }
 
+// out[j] = sum_r w[r] P[r][j] in f64 (w null: ones); partial: at least 1024 * ld doubles of scratch
+template <typename T>
+static void colsum_f64(const T* P, int64_t rows, int ld, const T* w, double* out, double* partial, hipStream_t s) {
+  int by = 256 / ld;
+  if (by < 1) by = 1;
+  int nblocks = (int)((rows + by * 8 - 1) / (by * 8));
+  if (nblocks > 1024) nblocks = 1024;
+  if (nblocks < 1) nblocks = 1;
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(nblocks), dim3(ld, by), (size_t)by * ld * sizeof(double), s, P, rows, ld, w, partial);
+  hipLaunchKernelGGL((colsum_final_kernel<double>), dim3(ld), dim3(64), 0, s, partial, nblocks, ld, out);
+}
+
 template <typename T, int NT>
 void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, hipStream_t s) {
   constexpr int NPAIR = NT * (NT + 1) / 2;
@@ -986,7 +1258,8 @@ void launch_gram(const T* P, int64_t rows, int ld, double* slabs, int nblocks, h
 
 template <typename T, int NTO>
 void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, int ldp_stride = 0,
-                       int ldm_stride = 0, int ldo_stride = 0, int accumulate = 0, int upper = 0) {
+                       int ldm_stride = 0, int ldo_stride = 0, int accumulate = 0, int upper = 0, int ncols_out = 0) {
+  if (ncols_out <= 0 || ncols_out > ldo) ncols_out = ldo;
   const size_t lds = (size_t)ld * ldo * sizeof(double);
   static LdsAttrState attr;
   if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&panel_gemm_kernel<T, NTO>), lds, attr);
@@ -1001,7 +1274,7 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
       if (blocks > 256) blocks = 256;
       if (blocks < 1) blocks = 1;
       hipLaunchKernelGGL((panel_gemm_kernel<T, NTO, 768>), dim3(blocks), dim3(768), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
-                         ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
+                         ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper, ncols_out);
       return;
     }
   }
@@ -1014,7 +1287,7 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
       int blocks = (int)((ntiles + 7) / 8);
       if (blocks > 1024) blocks = 1024;
       hipLaunchKernelGGL((panel_gemm_kernel<T, NTO, 512>), dim3(blocks), dim3(512), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
-                         ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
+                         ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper, ncols_out);
       return;
     }
   }
@@ -1022,7 +1295,7 @@ void launch_panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ld
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((panel_gemm_kernel<T, NTO>), dim3(blocks), dim3(256), lds, s, P, rows, ld, M, ldo, out, ldp_stride ? ldp_stride : ld,
-                     ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper);
+                     ldm_stride ? ldm_stride : ldo, ldo_stride ? ldo_stride : ldo, accumulate, upper, ncols_out);
 }
 
 }  // namespace
@@ -1036,10 +1309,48 @@ __global__ void gram_place_pair_kernel(const double* __restrict__ G2, int bi, in
   G[(int64_t)gr * ld + gc] = G2[i];
 }
 
+template <typename T, int NT>
+static void launch_gramv(T* P, int64_t rows, int ld, double* slabs, int nblocks, const PanelSource<T>* src, const T* w, bool want_sum,
+                         hipStream_t s) {
+  constexpr int NPAIR = NT * (NT + 1) / 2;
+  const size_t lds = NT > 6 ? 0 : (size_t)(NPAIR * 256 + 16 * NT) * sizeof(double);
+  if (src) {
+    hipLaunchKernelGGL((gramv_kernel<T, NT, true>), dim3(nblocks), dim3(256), lds, s, P, rows, ld, slabs, *src, w, want_sum ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL((gramv_kernel<T, NT, false>), dim3(nblocks), dim3(256), lds, s, P, rows, ld, slabs, PanelSource<T>{}, w, want_sum ? 1 : 0);
+  }
+}
+
 template <typename T>
-void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s) {
+void materialize(T* P, int64_t rows, int ld, const PanelSource<T>& src, hipStream_t s) {
+  if (rows == 0 || (src.parts == P && src.nsplit <= 1 && !src.mu)) return;
+  hipLaunchKernelGGL((materialize_kernel<T>), dim3(grid_for(rows * ld, 256)), dim3(256), 0, s, P, rows, ld, src);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void gram(T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s, const PanelSource<T>* src, const T* w, double* wsum) {
   SAPCA_CHECK(ld % 16 == 0 && ld >= 16 && (ld <= 128 || (ld % 64 == 0 && ld <= kMaxPanelWidth)), SAPCA_ERR_ARG,
               "gram: panel width must be a multiple of 16 up to 128, or of 64 up to 1024");
+  const int nt = ld / 16;
+  if (nt == 4 || nt == 8) {
+    // the 64 / 128-column panels of the staged sweeps: the producer's fix-up and the column sums ride in the read pass
+    if (src && nt == 8 && src->parts == P) {   // (four waves read a row there: not in place)
+      materialize(P, rows, ld, *src, s);
+      src = nullptr;
+    }
+    const int npair = nt * (nt + 1) / 2, slab_len = npair * 256 + 16 * nt;
+    int nblocks = (int)((rows + 15) / 16);
+    if (nblocks > 512) nblocks = 512;
+    if (nblocks < 1) nblocks = 1;
+    double* slabs = scratch.as<double>((size_t)nblocks * slab_len);
+    if (nt == 4) launch_gramv<T, 4>(P, rows, ld, slabs, nblocks, src, w, wsum != nullptr, s);
+    else launch_gramv<T, 8>(P, rows, ld, slabs, nblocks, src, w, wsum != nullptr, s);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((slab_len + 15) / 16), dim3(256), 0, s, slabs, nblocks, nt, ld, G, 1, wsum);
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
+  if (src) materialize(P, rows, ld, *src, s);
   if (ld > 128) {
     // wide panels: every pair (I < J) of 64-column blocks goes through the 128-wide kernel as the panel [P_I P_J]
     // (a lone block pairs with itself); the diagonal blocks are written by several pairs, with the same bits each time
@@ -1047,35 +1358,34 @@ void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStrea
     int nblocks = (int)((rows + 15) / 16);
     if (nblocks > 512) nblocks = 512;
     if (nblocks < 1) nblocks = 1;
-    double* slabs = scratch.as<double>((size_t)nblocks * npair * 256 + 128 * 128);
+    double* slabs = scratch.as<double>((size_t)nblocks * npair * 256 + 128 * 128 + (wsum ? (size_t)1024 * ld : 0));
     double* G2 = slabs + (size_t)nblocks * npair * 256;
     for (int bi = 0; bi < nb; ++bi)
       for (int bj = bi + 1; bj < nb; ++bj) {
         hipLaunchKernelGGL((gram_split_kernel<T, 8>), dim3(nblocks), dim3(256), 0, s, P + 64 * bi, rows, ld, slabs, P + 64 * bj);
-        hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, 8, 128, G2);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, 8, 128, G2, 0, (double*)nullptr);
         hipLaunchKernelGGL(gram_place_pair_kernel, dim3(64), dim3(256), 0, s, G2, bi, bj, ld, G);
       }
     SAPCA_HIP(hipGetLastError());
+    if (wsum) colsum_f64(P, rows, ld, w, wsum, G2 + 128 * 128, s);
     return;
   }
-  const int nt = ld / 16;
   const int npair = nt * (nt + 1) / 2;
   int nblocks = (int)((rows + 15) / 16);
   if (nblocks > 512) nblocks = 512;
   if (nblocks < 1) nblocks = 1;
-  double* slabs = scratch.as<double>((size_t)nblocks * npair * 256);
+  double* slabs = scratch.as<double>((size_t)nblocks * npair * 256 + (wsum ? (size_t)1024 * ld : 0));
   switch (nt) {
     case 1: launch_gram<T, 1>(P, rows, ld, slabs, nblocks, s); break;
     case 2: launch_gram<T, 2>(P, rows, ld, slabs, nblocks, s); break;
     case 3: launch_gram<T, 3>(P, rows, ld, slabs, nblocks, s); break;
-    case 4: launch_gram<T, 4>(P, rows, ld, slabs, nblocks, s); break;
     case 5: launch_gram<T, 5>(P, rows, ld, slabs, nblocks, s); break;
     case 6: launch_gram<T, 6>(P, rows, ld, slabs, nblocks, s); break;
-    case 7: launch_gram<T, 7>(P, rows, ld, slabs, nblocks, s); break;
-    default: launch_gram<T, 8>(P, rows, ld, slabs, nblocks, s); break;
+    default: launch_gram<T, 7>(P, rows, ld, slabs, nblocks, s); break;
   }
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, nt, ld, G);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((npair * 256 + 15) / 16), dim3(256), 0, s, slabs, nblocks, nt, ld, G, 0, (double*)nullptr);
   SAPCA_HIP(hipGetLastError());
+  if (wsum) colsum_f64(P, rows, ld, w, wsum, slabs + (size_t)nblocks * npair * 256, s);
 }
 
 // l > 128: the factorisation runs on the host (the one-workgroup kernels keep the matrix in LDS); same pivot floor, same
@@ -1132,16 +1442,24 @@ static void chol_inv_host(const double* G, int l, int ld, double* R, double* Rin
   SAPCA_HIP(hipStreamSynchronize(s));   // (the host vectors go out of scope)
 }
 
-void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s) {
+void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s, const double* wsum, float* vec32, double* vec64) {
   static const bool general_only = getenv("SAPCA_CHOL_GENERAL") != nullptr;
+  if (!vec32 && !vec64) wsum = nullptr;
+  auto tvec = [&] {   // (the variants that do not carry the product in their own epilogue)
+    if (!wsum) return;
+    if (vec32) hipLaunchKernelGGL((rinv_tvec_kernel<float>), dim3((ld + 63) / 64), dim3(64), 0, s, Rinv, l, ld, wsum, vec32);
+    if (vec64) hipLaunchKernelGGL((rinv_tvec_kernel<double>), dim3((ld + 63) / 64), dim3(64), 0, s, Rinv, l, ld, wsum, vec64);
+    SAPCA_HIP(hipGetLastError());
+  };
   if (l > 128) {
     chol_inv_host(G, l, ld, R, Rinv, info, s);
+    tvec();
     return;
   }
-  if (l <= 64 && !general_only) {
+  if (l <= 64 && ld >= l && ld <= 256 && !general_only) {
     static LdsAttrState attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_blocked_kernel), kCholBlockedLds, attr);
-    hipLaunchKernelGGL(chol_inv_blocked_kernel, dim3(1), dim3(256), kCholBlockedLds, s, G, l, ld, R, Rinv, info);
+    hipLaunchKernelGGL(chol_inv_blocked_kernel, dim3(1), dim3(256), kCholBlockedLds, s, G, l, ld, R, Rinv, info, wsum, vec32, vec64);
     SAPCA_HIP(hipGetLastError());
     return;
   }
@@ -1150,6 +1468,7 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_blocked128_kernel), kChol128Lds, attr);
     hipLaunchKernelGGL(chol_inv_blocked128_kernel, dim3(1), dim3(256), kChol128Lds, s, G, l, R, Rinv, info);
     SAPCA_HIP(hipGetLastError());
+    tvec();
     return;
   }
   const size_t lds = ((size_t)l * (l + 1) + l) * sizeof(double);
@@ -1157,16 +1476,19 @@ void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info
   if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&chol_inv_kernel), lds, attr);
   hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(256), lds, s, G, l, ld, R, Rinv, info);
   SAPCA_HIP(hipGetLastError());
+  tvec();
 }
 
 template <typename T, int NTO>
 static void panel_gemm_block(const T* P, int64_t rows, int kd, const double* M, int nd, T* out, hipStream_t s, int ldp, int ldm, int ldo, int acc,
-                             int upper) {
-  launch_panel_gemm<T, NTO>(P, rows, kd, M, nd, out, s, ldp, ldm, ldo, acc, upper);
+                             int upper, int ncols_out) {
+  launch_panel_gemm<T, NTO>(P, rows, kd, M, nd, out, s, ldp, ldm, ldo, acc, upper, ncols_out);
 }
 
 template <typename T>
-void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, bool upper) {
+void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, bool upper, int out_stride, int out_cols) {
+  if (out_stride <= 0) out_stride = ldo;
+  if (out_cols <= 0 || out_cols > ldo) out_cols = ldo;
   SAPCA_CHECK(ld % 16 == 0 && ldo % 16 == 0 && ldo >= 16 && ld <= kMaxPanelWidth && ldo <= kMaxPanelWidth, SAPCA_ERR_ARG,
               "panel_gemm: unsupported panel width");
   if (rows == 0) return;
@@ -1176,10 +1498,12 @@ void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* o
     SAPCA_CHECK(out != P, SAPCA_ERR_ARG, "panel_gemm: wide panels are not multiplied in place");
     for (int j0 = 0; j0 < ldo; j0 += 128) {
       const int nd = std::min(128, ldo - j0);
+      if (out_cols <= j0) break;
       bool first = true;
       for (int i0 = 0; i0 < ld; i0 += 128) {
         const int kd = std::min(128, ld - i0);
         if (upper && i0 >= j0 + nd) break;
+        const int nco = std::min(nd, out_cols - j0);
         const int acc = first ? 0 : 1;
         const int diag = (upper && i0 == j0) ? 1 : 0;   // (a diagonal block of an upper triangular M is upper triangular itself)
         first = false;
@@ -1187,30 +1511,30 @@ void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* o
         const double* Mb = M + (size_t)i0 * ldo + j0;
         T* ob = out + j0;
         switch (nd / 16) {
-          case 1: panel_gemm_block<T, 1>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          case 2: panel_gemm_block<T, 2>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          case 3: panel_gemm_block<T, 3>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          case 4: panel_gemm_block<T, 4>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          case 5: panel_gemm_block<T, 5>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          case 6: panel_gemm_block<T, 6>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          case 7: panel_gemm_block<T, 7>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
-          default: panel_gemm_block<T, 8>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, ldo, acc, diag); break;
+          case 1: panel_gemm_block<T, 1>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          case 2: panel_gemm_block<T, 2>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          case 3: panel_gemm_block<T, 3>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          case 4: panel_gemm_block<T, 4>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          case 5: panel_gemm_block<T, 5>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          case 6: panel_gemm_block<T, 6>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          case 7: panel_gemm_block<T, 7>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
+          default: panel_gemm_block<T, 8>(Pb, rows, kd, Mb, nd, ob, s, ld, ldo, out_stride, acc, diag, nco); break;
         }
       }
     }
     SAPCA_HIP(hipGetLastError());
     return;
   }
-  SAPCA_CHECK(out != P || ldo == ld, SAPCA_ERR_ARG, "panel_gemm: in-place needs ldo == ld");
+  SAPCA_CHECK(out != P || (ldo == ld && out_stride == ldo), SAPCA_ERR_ARG, "panel_gemm: in-place needs ldo == ld");
   switch (ldo / 16) {
-    case 1: launch_panel_gemm<T, 1>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    case 2: launch_panel_gemm<T, 2>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    case 3: launch_panel_gemm<T, 3>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    case 4: launch_panel_gemm<T, 4>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    case 5: launch_panel_gemm<T, 5>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    case 6: launch_panel_gemm<T, 6>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    case 7: launch_panel_gemm<T, 7>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
-    default: launch_panel_gemm<T, 8>(P, rows, ld, M, ldo, out, s, 0, 0, 0, 0, upper ? 1 : 0); break;
+    case 1: launch_panel_gemm<T, 1>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    case 2: launch_panel_gemm<T, 2>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    case 3: launch_panel_gemm<T, 3>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    case 4: launch_panel_gemm<T, 4>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    case 5: launch_panel_gemm<T, 5>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    case 6: launch_panel_gemm<T, 6>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    case 7: launch_panel_gemm<T, 7>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
+    default: launch_panel_gemm<T, 8>(P, rows, ld, M, ldo, out, s, 0, 0, out_stride, 0, upper ? 1 : 0, out_cols); break;
   }
   SAPCA_HIP(hipGetLastError());
 }
@@ -1257,8 +1581,9 @@ void rank1_subtract(T* Z, int64_t rows, int ld, const T* mu, const T* svec, hipS
 }
 
 template <typename T>
-void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s) {
+void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s, const double** sign_out) {
   double* sign = scratch.as<double>(k);
+  if (sign_out) *sign_out = sign;
   hipLaunchKernelGGL((flip_sign_kernel<T>), dim3(k), dim3(256), 0, s, VtT, n, ld, sign);
   hipLaunchKernelGGL((flip_transpose_kernel<T>), dim3(grid_for((int64_t)k * n, 256)), dim3(256), 0, s, VtT, n, ld, k,
                      sign, components);
@@ -1269,6 +1594,18 @@ template <typename T>
 void scaled_transpose(const T* comps, int64_t n, int k, const double* scale, T* W, int ld, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL((scaled_transpose_kernel<T>), dim3(grid_for(n * ld, 256)), dim3(256), 0, s, comps, n, k, scale, W, ld);
+  SAPCA_HIP(hipGetLastError());
+}
+
+template <typename T>
+void scale_rows(const T* P, int64_t rows, int ld, const double* scale, T* out, hipStream_t s) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL((scale_rows_kernel<T>), dim3(grid_for(rows * ld, 256)), dim3(256), 0, s, P, rows, ld, scale, out);
+  SAPCA_HIP(hipGetLastError());
+}
+
+void scale_columns(double* M, int rows, int ld, int k, const double* sign, hipStream_t s) {
+  hipLaunchKernelGGL(scale_columns_kernel, dim3((rows * ld + 255) / 256), dim3(256), 0, s, M, rows, ld, k, sign);
   SAPCA_HIP(hipGetLastError());
 }
 
@@ -1301,11 +1638,13 @@ void add_padding(const T* in, int64_t rows, int ncols, T* out, int ld, hipStream
 }
 
 #define INSTANTIATE(T)                                                                            \
-  template void gram<T>(const T*, int64_t, int, double*, DevBuf&, hipStream_t);                   \
-  template void panel_gemm<T>(const T*, int64_t, int, const double*, int, T*, hipStream_t, bool); \
+  template void gram<T>(T*, int64_t, int, double*, DevBuf&, hipStream_t, const PanelSource<T>*, const T*, double*); \
+  template void materialize<T>(T*, int64_t, int, const PanelSource<T>&, hipStream_t);             \
+  template void panel_gemm<T>(const T*, int64_t, int, const double*, int, T*, hipStream_t, bool, int, int); \
   template void weighted_colsum<T>(const T*, int64_t, int, const T*, T*, DevBuf&, hipStream_t);   \
   template void rank1_subtract<T>(T*, int64_t, int, const T*, const T*, hipStream_t);             \
-  template void flip_transpose<T>(const T*, int64_t, int, int, T*, DevBuf&, hipStream_t);         \
+  template void flip_transpose<T>(const T*, int64_t, int, int, T*, DevBuf&, hipStream_t, const double**); \
+  template void scale_rows<T>(const T*, int64_t, int, const double*, T*, hipStream_t);            \
   template void scaled_transpose<T>(const T*, int64_t, int, const double*, T*, int, hipStream_t); \
   template void fill_zero<T>(T*, int64_t, hipStream_t);                                           \
   template void convert_from_f64<T>(const double*, T*, int64_t, hipStream_t);                     \

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <thread>
 
 #include "lanczos.h"
@@ -31,6 +32,7 @@ struct SmallLayout {
   size_t doubles() const { return 6 * W * W + 64 + 4 * W; }
   size_t info_at() const { return 6 * W * W; }
   size_t cvec_at() const { return 6 * W * W + 64; }
+  size_t wsum_at() const { return 6 * W * W + 64 + 2 * W; }   // W doubles behind c | s: the column sums a Gram pass gathers
 };
 
 enum Cat { C_PREPARE, C_STATS, C_SPMM, C_SPMMT, C_ORTHO, C_SMALL, C_LANCZOS, C_TRANSFORM, C_COMM, C_COUNT };
@@ -635,9 +637,17 @@ void Engine<T>::finish_statistics(H& h) {
 // ------------------------------------------------------------------------------------------
 template <typename T>
 void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2,
-                          int passes_hint) {
-  if (normalizer == SAPCA_NORM_NONE) return;
+                          int passes_hint, const k::PanelSource<T>* src, const T* w, T* vec_out) {
+  // src (nullable): the panel is still as its producer left it (slabs of a split sweep, the centring term not yet
+  // subtracted): the first Gram applies that on its way through.  vec_out (nullable): receives sum_r w[r] Q[r][:] of the
+  // normalised panel Q = P R^-1 (w null: ones) -- the centring vector of the sweep that reads Q next -- computed as
+  // R^-T (P^T w) from sums gathered in the Gram's read pass, not from another pass over Q.
   hipStream_t s = h.stream;
+  if (normalizer == SAPCA_NORM_NONE) {
+    if (src) k::materialize(P, rows, ld, *src, s);
+    if (vec_out) k::weighted_colsum(P, rows, ld, w, vec_out, h.scratch2, s);
+    return;
+  }
   Scope sc(h, C_ORTHO);
   const SmallLayout lay(ld);
   double* base = h.small.as<double>(lay.doubles());
@@ -645,6 +655,7 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
   double* Rinv = base + (size_t)ld * ld;
   double* Rtmp = base + (size_t)2 * ld * ld;
   int* info = reinterpret_cast<int*>(base + lay.info_at());
+  double* wsum = vec_out ? base + lay.wsum_at() : nullptr;
   // QR -> CholeskyQR2 (orthonormal to working precision); LU -> one pass: a well-conditioned
   // basis of the same span, which is all the reference's LU normaliser provides.  Between power
   // iterations only the span matters (the next sweep re-mixes the basis), so the intermediate QR
@@ -652,10 +663,11 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
   // factorisation of B^T always get both passes.
   const int passes = passes_hint > 0 ? passes_hint : (normalizer == SAPCA_NORM_QR ? 2 : 1);
   for (int pass = 0; pass < passes; ++pass) {
-    k::gram(P, rows, ld, G, h.scratch2, s);
+    k::gram(P, rows, ld, G, h.scratch2, s, pass == 0 ? src : nullptr, w, wsum);
     if (sharded && h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(G, (uint64_t)ld * ld, 1, s); }
     double* Rout = pass == 0 ? (R1 ? R1 : Rtmp) : (R2 ? R2 : Rtmp);
-    k::chol_inv(G, l, ld, Rout, Rinv, info, s);
+    k::chol_inv(G, l, ld, Rout, Rinv, info, s, wsum, sizeof(T) == 4 ? reinterpret_cast<float*>(vec_out) : nullptr,
+                sizeof(T) == 8 ? reinterpret_cast<double*>(vec_out) : nullptr);
     if (ld <= 128) {
       k::panel_gemm(P, rows, ld, Rinv, ld, P, s, true);   // (R^-1 is upper triangular: its zero blocks are skipped)
     } else {   // wide panels: block by block into a second panel, then back (R^-1 is upper triangular)
@@ -719,27 +731,26 @@ void Engine<T>::fit_randomized(H& h) {
     k::gaussian_panel(X, n_used, l, ld, h.opt.random_seed, s);
   }
 
+  // Centring vectors.  c = X^T mu (sweep_A) and the column sums 1^T Y (sweep_At) belong to a panel that has just been
+  // normalised: normalize() delivers them from sums gathered in its Gram pass (vec_out), so no kernel re-reads the
+  // normalised panel for them; only the very first c (of Omega) is summed here.
+  bool cvec_ready = false;
   auto sweep_A = [&]() {  // Y = Ac X   (R8)
-    if (center) k::weighted_colsum(X, n_used, ld, mu, cvec, h.scratch2, s);
+    if (center && !cvec_ready) k::weighted_colsum(X, n_used, ld, mu, cvec, h.scratch2, s);
+    cvec_ready = false;
     Scope sc(h, C_SPMM);
     k::spmm(A, &h.tiled_a, X, ld, Y, ld, ld, center ? cvec : nullptr, variant, h.split_scratch, s);
   };
-  // Multi-rank fits: the n x l panel of an A^T sweep is the one bandwidth-relevant collective.  Where the
-  // operator allows it the sweep runs in two pieces of its output rows, each cut finely enough to keep (nearly) every CU
-  // busy, and the first piece is all-reduced on a side stream while the second is swept; the second piece's collective
-  // carries the column sums.  A few CUs are left free for the collective's own kernels (a sweep workgroup takes all of a
-  // CU's LDS, nothing else fits beside it).  SAPCA_AT_OVERLAP=0 switches it off.
   std::vector<int64_t> piece_rows;
   bool overlap = false;
   int64_t cut = 0;   // rows [0, cut) of the panel are all-reduced behind the first piece, the rest behind the second
   int piece_wgs = 240;
   h.at_sweep_pieces = 1u;
   if constexpr (sizeof(T) == 4) {
-    // Default: on for the callback / in-process transports (tested with two and three ranks), off for RCCL until the library's
-    // own RCCL binding has run with more than one rank on real hardware (two streams then issue on one communicator);
-    // SAPCA_AT_OVERLAP=1 / 0 forces it either way.
+    // Default: on wherever the side stream has a lane of its own -- the callback / in-process transports, and RCCL through the
+    // duplicate communicator made at init (two streams never issue on one communicator).  SAPCA_AT_OVERLAP=0 switches it off.
     const char* ov = getenv("SAPCA_AT_OVERLAP");   // (read per fit: the tests switch it)
-    const bool overlap_off = ov != nullptr ? atoi(ov) == 0 : h.comm.mode == Comm::RCCL;
+    const bool overlap_off = (ov != nullptr && atoi(ov) == 0) || !h.comm.has_side_lane();
     if (h.comm.active() && !overlap_off && variant != 1) {
       // The pieces are whole row blocks of this rank's operator, and ranks cut their blocks differently (the block count
       // follows the shard's own tile count): the ranks agree on one row count -- the smallest first piece, 0 if any rank
@@ -768,8 +779,13 @@ void Engine<T>::fit_randomized(H& h) {
       }
     }
   }
-  auto sweep_At = [&]() {  // X = Ac^T Y   (R9); partial products are summed over ranks
-    T* sv = h.comm.active() ? X + (size_t)n_used * ld : svec;   // one collective carries the l column sums of this rank's Y too
+  // one collective carries the l column sums of this rank's Y too: they live in the row behind the panel then
+  T* const sv = h.comm.active() ? X + (size_t)n_used * ld : svec;
+  // X = Ac^T Y   (R9); partial products are summed over ranks.  The panel is left as the sweep produced it: `src` says what
+  // the next pass over X -- the Gram of its normalisation, or of the small SVD -- still has to apply (slabs of a sweep
+  // whose tile range was split over workgroups, the centring term mu (1^T Y)^T).  sv_ready: the normaliser of Y delivered 1^T Y.
+  auto sweep_At = [&](bool sv_ready, k::PanelSource<T>& src) {
+    src = k::PanelSource<T>();
     if constexpr (sizeof(T) == 4) {
       if (overlap) {
         const int wgs = piece_wgs;
@@ -780,37 +796,42 @@ void Engine<T>::fit_randomized(H& h) {
           SAPCA_HIP(hipEventRecord(h.ev_piece, s));
           k::spmm_tiled_piece(h.tiled_at, 1, 2, wgs, r1, n_used - r1, Y, ld, X, ld, ld, h.split_scratch2, s);
         }
-        if (center) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
+        if (center && !sv_ready) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
         {
           Scope cs(h, C_COMM);   // (device time from the first piece's collective being possible to the last one's end)
           SAPCA_HIP(hipStreamWaitEvent(h.stream_comm, h.ev_piece, 0));
-          h.comm.allreduce(X, (uint64_t)cut * ld, kDtype, h.stream_comm);   // (cut <= r1: rows this rank has finished)
+          h.comm.allreduce(X, (uint64_t)cut * ld, kDtype, h.stream_comm, 1);   // (cut <= r1: rows this rank has finished)
           SAPCA_HIP(hipEventRecord(h.ev_comm, h.stream_comm));
           h.comm.allreduce(X + (size_t)cut * ld, (uint64_t)(n_used - cut) * ld + (center ? (uint64_t)ld : 0), kDtype, s);
           SAPCA_HIP(hipStreamWaitEvent(s, h.ev_comm, 0));
         }
-        if (center) k::rank1_subtract(X, n_used, ld, mu, sv, s);
+        src.parts = X; src.nsplit = 1;
+        if (center) { src.mu = mu; src.sv = sv; }
         return;
       }
     }
     {
       Scope sc(h, C_SPMMT);
-      k::spmm(At, &h.tiled_at, Y, ld, X, ld, ld, (const T*)nullptr, variant, h.split_scratch, s);
+      // (one rank: the slabs may stay unsummed; several: the collective needs the sum)
+      k::spmm(At, &h.tiled_at, Y, ld, X, ld, ld, (const T*)nullptr, variant, h.split_scratch, s, h.comm.active() ? nullptr : &src);
     }
-    if (center) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
+    if (!src.parts) { src.parts = X; src.nsplit = 1; }
+    if (center && !sv_ready) k::weighted_colsum(Y, m, ld, (const T*)nullptr, sv, h.scratch2, s);
     if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(X, (uint64_t)n_used * ld + (center ? (uint64_t)ld : 0), kDtype, s); }
-    if (center) k::rank1_subtract(X, n_used, ld, mu, sv, s);
+    if (center) { src.mu = mu; src.sv = sv; }
   };
 
+  k::PanelSource<T> src;
   for (int it = 0; it < q; ++it) {
     sweep_A();
-    normalize(h, Y, m, l, ld, norm, true, nullptr, nullptr, 1);
-    sweep_At();
-    normalize(h, X, n_used, l, ld, norm, false, nullptr, nullptr, 1);
+    normalize(h, Y, m, l, ld, norm, true, nullptr, nullptr, 1, nullptr, nullptr, center ? sv : nullptr);
+    sweep_At(true, src);
+    normalize(h, X, n_used, l, ld, norm, false, nullptr, nullptr, 1, &src, mu, center ? cvec : nullptr);
+    cvec_ready = center;
   }
   sweep_A();
-  normalize(h, Y, m, l, ld, SAPCA_NORM_QR, true, nullptr, nullptr);  // Q = qr(Y): always orthonormal
-  sweep_At();                                                       // X = B^T = Ac^T Q  (n_used x l)
+  normalize(h, Y, m, l, ld, SAPCA_NORM_QR, true, nullptr, nullptr, 0, nullptr, nullptr, center ? sv : nullptr);  // Q = qr(Y): always orthonormal
+  sweep_At(true, src);                                              // X = B^T = Ac^T Q  (n_used x l), completed by the Gram below
 
   // R11 (f32): SVD of B through the l x l Gram of B^T: G = B B^T = Uh S^2 Uh^T (f64, MFMA + a host
   // eigensolver), vt = (B^T Uh S^-1)^T.  The Gram squares the condition number, so sigma_i is good to
@@ -822,7 +843,7 @@ void Engine<T>::fit_randomized(H& h) {
   if (gram_route) {
     Scope sc(h, C_SMALL);
     double* G = small;
-    k::gram(X, n_used, ld, G, h.scratch2, s);
+    k::gram(X, n_used, ld, G, h.scratch2, s, &src);
     const int ldk = (int)round_up(k, 16);
     if (k::sym_eig_device_ok(l)) {
       // (opt-in experiment, SAPCA_EIG_DEVICE=1: slower than the host path below -- see sym_eig_device_ok)
@@ -847,39 +868,20 @@ void Engine<T>::fit_randomized(H& h) {
     // page-locked staging owned by the handle: G comes back and M goes out without the runtime's bounce buffers, and M
     // outlives this call -- nothing here waits for the device after the eigensolver
     double* g = static_cast<double*>(h.small_host.ensure(((size_t)ld * ld + (size_t)ld * ldk + 2) * sizeof(double)));
-    double* M = g + (size_t)ld * ld;
-    int* info_pinned = reinterpret_cast<int*>(M + (size_t)ld * ldk);
+    int* info_pinned = reinterpret_cast<int*>(g + (size_t)ld * ld + (size_t)ld * ldk);
     SAPCA_HIP(hipMemcpyAsync(g, G, (size_t)ld * ld * sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipMemcpyAsync(info_pinned, info, sizeof(int), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipStreamSynchronize(s));
-    info_host = *info_pinned;
-    std::vector<double> Gl((size_t)l * l), w, Vt;
-    for (int i = 0; i < l; ++i)
-      for (int j = 0; j < l; ++j) Gl[(size_t)i * l + j] = g[(size_t)i * ld + j];
-    const auto tj0 = std::chrono::steady_clock::now();
-    SAPCA_CHECK(sym_eigh_desc(Gl, l, w, Vt), SAPCA_ERR_SVD, "Randomized SVD computation failed: eigensolver did not converge");
-    if (h.opt.verbose)
-      fprintf(stderr, "sapca: host eigensolver of the %d x %d Gram: %.3f ms\n", l, l,
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count());
-    std::vector<double> sv((size_t)l);
-    for (int i = 0; i < l; ++i) {
-      SAPCA_CHECK(std::isfinite(w[i]), SAPCA_ERR_SVD, "Randomized SVD computation failed: non-finite singular value");
-      sv[i] = std::sqrt(std::max(w[i], 0.0));
+    h.small_l = l;
+    h.small_ld = ld;
+    if (h.defer_small) {
+      // fit_transform: the host eigensolver runs while the GPU sweeps the projection with the un-rotated panel (transform():
+      // T = [Ac diag(cnt) B^T] M), instead of in front of an idle GPU
+      if (!h.ev_small) SAPCA_HIP(hipEventCreateWithFlags(&h.ev_small, hipEventDisableTiming));
+      SAPCA_HIP(hipEventRecord(h.ev_small, s));
+      h.small_pending = true;
+      return;
     }
-    std::fill(M, M + (size_t)ld * ldk, 0.0);
-    const double tiny = sv[0] * 1e-12;
-    for (int j = 0; j < k; ++j) {
-      if (!(sv[j] > tiny)) continue;   // numerically rank-deficient direction: a zero component, sigma ~ 0
-      const double inv = 1.0 / sv[j];
-      for (int i = 0; i < l; ++i) M[(size_t)i * ldk + j] = Vt[(size_t)j * l + i] * inv;
-    }
-    SAPCA_HIP(hipMemcpyAsync(Mdev, M, (size_t)ld * ldk * sizeof(double), hipMemcpyHostToDevice, s));
-    T* VtT = h.panel_w.as<T>((size_t)std::max<int64_t>(n_used, 1) * ldk);
-    k::panel_gemm(X, n_used, ld, Mdev, ldk, VtT, s);
-    T* comps = h.components_dev.as<T>((size_t)k * std::max<int64_t>(n_used, 1));
-    k::flip_transpose(VtT, n_used, ldk, k, comps, h.scratch2, s);  // R13
-    h.sing.assign(sv.begin(), sv.begin() + k);
-    h.chol_regularised = info_host;
+    finish_small_svd(h, nullptr);
     return;
   }
 
@@ -887,7 +889,7 @@ void Engine<T>::fit_randomized(H& h) {
   std::vector<double> r1((size_t)ld * ld), r2((size_t)ld * ld);
   {
     Scope sc(h, C_SMALL);
-    normalize(h, X, n_used, l, ld, SAPCA_NORM_QR, false, R1, R2);
+    normalize(h, X, n_used, l, ld, SAPCA_NORM_QR, false, R1, R2, 0, &src);
     SAPCA_HIP(hipMemcpyAsync(r1.data(), R1, r1.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipMemcpyAsync(r2.data(), R2, r2.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     SAPCA_HIP(hipMemcpyAsync(&info_host, info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -921,6 +923,65 @@ void Engine<T>::fit_randomized(H& h) {
   h.chol_regularised = info_host;
 }
 
+// R11 (f32), host half: eigen-decomposition of the l x l Gram staged in small_host by fit_randomized, the factor
+// M = Uh S^-1 back to the device, vt = (B^T M)^T, svd_flip (R13).  Called at the end of fit_randomized, or -- fit_transform,
+// `small_pending` -- from transform() once the projection sweep is queued.  sign_out: the device address of the k flip signs.
+template <typename T>
+void Engine<T>::finish_small_svd(H& h, const double** sign_out) {
+  hipStream_t s = h.stream;
+  const bool deferred = h.small_pending;
+  h.small_pending = false;
+  const int l = h.small_l, ld = h.small_ld, k = (int)h.opt.n_components;
+  const int64_t n_used = h.a_used.cols;
+  const int ldk = (int)round_up(k, 16);
+  const SmallLayout lay(ld);
+  double* small = h.small.as<double>(lay.doubles());
+  double* Mdev = small + (size_t)5 * ld * ld;
+  T* X = h.panel_x.ptr<T>();
+  try {
+    std::unique_ptr<Scope> sc(deferred ? new Scope(h, C_SMALL) : nullptr);   // (not deferred: inside fit_randomized's own span)
+    double* g = static_cast<double*>(h.small_host.p);
+    double* M = g + (size_t)ld * ld;
+    const int* info_pinned = reinterpret_cast<const int*>(M + (size_t)ld * ldk);
+    if (deferred) SAPCA_HIP(hipEventSynchronize(h.ev_small));
+    else SAPCA_HIP(hipStreamSynchronize(s));
+    const int info_host = *info_pinned;
+    std::vector<double> Gl((size_t)l * l), w, Vt;
+    for (int i = 0; i < l; ++i)
+      for (int j = 0; j < l; ++j) Gl[(size_t)i * l + j] = g[(size_t)i * ld + j];
+    const auto tj0 = std::chrono::steady_clock::now();
+    SAPCA_CHECK(sym_eigh_desc(Gl, l, w, Vt), SAPCA_ERR_SVD, "Randomized SVD computation failed: eigensolver did not converge");
+    if (h.opt.verbose)
+      fprintf(stderr, "sapca: host eigensolver of the %d x %d Gram: %.3f ms\n", l, l,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count());
+    std::vector<double> sv((size_t)l);
+    for (int i = 0; i < l; ++i) {
+      SAPCA_CHECK(std::isfinite(w[i]), SAPCA_ERR_SVD, "Randomized SVD computation failed: non-finite singular value");
+      sv[i] = std::sqrt(std::max(w[i], 0.0));
+    }
+    std::fill(M, M + (size_t)ld * ldk, 0.0);
+    const double tiny = sv[0] * 1e-12;
+    for (int j = 0; j < k; ++j) {
+      if (!(sv[j] > tiny)) continue;   // numerically rank-deficient direction: a zero component, sigma ~ 0
+      const double inv = 1.0 / sv[j];
+      for (int i = 0; i < l; ++i) M[(size_t)i * ldk + j] = Vt[(size_t)j * l + i] * inv;
+    }
+    SAPCA_HIP(hipMemcpyAsync(Mdev, M, (size_t)ld * ldk * sizeof(double), hipMemcpyHostToDevice, s));
+    T* VtT = h.panel_w.as<T>((size_t)std::max<int64_t>(n_used, 1) * ldk);
+    k::panel_gemm(X, n_used, ld, Mdev, ldk, VtT, s);
+    T* comps = h.components_dev.as<T>((size_t)k * std::max<int64_t>(n_used, 1));
+    k::flip_transpose(VtT, n_used, ldk, k, comps, h.scratch2, s, sign_out);  // R13
+    h.sing.assign(sv.begin(), sv.begin() + k);
+    h.chol_regularised = info_host;
+  } catch (...) {
+    if (deferred) {   // the fit had been reported as done: take that back
+      h.fitted = false;
+      h.finish_pending = false;
+    }
+    throw;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // R12: Lanczos on the raw operator (no centring: quirk Q1).
 // ------------------------------------------------------------------------------------------
@@ -938,6 +999,10 @@ void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
   hipStream_t s = h.stream;
   h.finish_pending = false;
   h.sing_pending = 0;
+  h.small_pending = false;
+  // fit_transform of an unmasked f32 randomized fit: the small SVD's host half is held back until transform() has queued
+  // the projection sweep (masked fits finish first, see below)
+  h.defer_small = defer_finish && h.mask.empty() && h.opt.method == SAPCA_RANDOM && sizeof(T) == 4;
   h.spans.clear();
   h.comm.host_ms = 0;
   h.timer.begin_collect(s, h.opt.collect_timings != 0);
@@ -996,6 +1061,7 @@ void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
 template <typename T>
 void Engine<T>::finish_fit(H& h) {
   if (!h.finish_pending) return;
+  if (h.small_pending) finish_small_svd(h, nullptr);   // (a projection that failed before it reached the held-back half)
   h.finish_pending = false;
   hipStream_t s = h.stream;
   const int total_ev = h.fit_total_ev;
@@ -1076,7 +1142,10 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
   int ldk = (int)round_up(k, 16);
   const bool center = h.opt.center != 0;
   const bool ref_sem = h.opt.transform_semantics == SAPCA_TRANSFORM_REFERENCE;
-  if (m == 0) return;
+  if (m == 0) {   // (a rank with an empty shard still completes a fit whose tail was held back)
+    finish_fit(h);
+    return;
+  }
   {
     Scope sc(h, C_TRANSFORM);
     H::PrepKey key;
@@ -1114,10 +1183,37 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
         if (h.comm.active()) h.comm.allreduce(d_cnt, (uint64_t)n, 1, s);
       }
     }
+    const T* mu = h.mean_used_dev.ptr<T>();
+    if (h.small_pending && prepared && !masked) {
+      // fit_transform, f32 randomized: the fit stopped in front of the host eigensolver.  The projection is linear in the
+      // components: with vt^T = B^T M (M = Uh S^-1 diag(sign), l x k) the reference's t = Ac diag(cnt) vt^T (Q2; cnt = 1 for the
+      // centred semantics) is [Ac diag(cnt) B^T] M -- the sweep runs on the un-rotated n x l panel while the host solves the
+      // l x l eigenproblem, and one m x l by l x k panel product rotates its result.  (B^T = panel_x; Q = panel_y is free.)
+      const int l = h.small_l, ld = h.small_ld;
+      const SmallLayout lay(ld);
+      double* small = h.small.as<double>(lay.doubles());
+      T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
+      double* Mdev = small + (size_t)5 * ld * ld;
+      const T* X = h.panel_x.ptr<T>();
+      T* Xs = h.panel_xs.as<T>((size_t)n_used * ld);
+      T* Tp = h.panel_y.as<T>((size_t)m * ld);
+      const TiledOp* topl = h.tiled_a.valid ? &h.tiled_a : nullptr;
+      k::scale_rows(X, n_used, ld, ref_sem ? d_cnt : nullptr, Xs, s);
+      if (center) k::weighted_colsum(Xs, n_used, ld, mu, cvec, h.scratch2, s);
+      k::spmm(Au, topl, Xs, ld, Tp, ld, ld, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
+      (void)l;
+      const double* sign = nullptr;
+      finish_small_svd(h, &sign);   // (waits for the Gram's copy only; the sweep above is running)
+      const int ldm = (int)round_up(k, 16);
+      k::scale_columns(Mdev, ld, ldm, k, sign, s);
+      k::panel_gemm(Tp, m, ld, Mdev, ldm, d_out, s, false, k, k);
+      goto projected;
+    }
+    if (h.small_pending) finish_small_svd(h, nullptr);
+    {
     const SmallLayout lay(ldk);
     double* small = h.small.as<double>(lay.doubles());
     T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
-    const T* mu = h.mean_used_dev.ptr<T>();
     const T* comps = h.components_dev.ptr<T>();
     T* W = h.panel_w.as<T>((size_t)n_used * ldk);
     if (ref_sem && !masked) {
@@ -1147,6 +1243,8 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
       k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
     }
+    }
+  projected:;
   }
   SAPCA_HIP(hipStreamSynchronize(s));
   finish_fit(h);   // (fit_transform: the fit's host-side tail, held back until the projection was queued)

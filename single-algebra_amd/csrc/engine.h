@@ -68,6 +68,11 @@ struct sapca_handle_s {
   sapca::PinnedBuf small_host;    // the l x l Gram on its way to the host eigensolver, its factor on the way back
   int fit_total_ev = -1;
   bool finish_pending = false;    // fit() returned with its host-side tail still to run (fit_transform)
+  // fit_transform (unmasked f32 randomized fits): fit() returns in front of the host eigensolver of the l x l Gram and
+  // transform() runs it once the projection sweep is queued (engine.cpp, finish_small_svd)
+  bool defer_small = false, small_pending = false;
+  int small_l = 0, small_ld = 0;
+  hipEvent_t ev_small = nullptr;
   int sing_pending = 0;           // l: the singular values of the device eigensolver are still on their way (read in finish_fit)
   sapca::PinnedBuf lanczos_host;  // alpha | beta of the Lanczos tridiagonal, read back at each convergence check
   bool stats_pending = false;
@@ -93,7 +98,7 @@ struct sapca_handle_s {
   sapca::DevBuf drop_stats, drop_tmp;                              // their sums (sum | sumsq, full width) and the sort's work space
   sapca::DevBuf drop_col, drop_val;                                // the entries the compaction dropped, as (column, value) pairs
   sapca::DevBuf scratch, scratch2;
-  sapca::DevBuf panel_x, panel_y, panel_w, panel_wide;   // (panel_wide: the out-of-place product of a panel wider than 128 columns)
+  sapca::DevBuf panel_x, panel_y, panel_w, panel_xs, panel_wide;   // (panel_wide: the out-of-place product of a panel wider than 128 columns)
   sapca::DevBuf small;                                           // G, R1, R2, Rinv, M, cvec, svec, info
   sapca::DevBuf stats;                                           // sum, sumsq, cnt (f64, n each)
   sapca::DevBuf mean_used_dev, o2m_dev, sel_rows_dev;
@@ -119,6 +124,7 @@ struct Engine {
   static void prepare(H& h, const CsrView<T>& A);
   static void finish_statistics(H& h);   // host side of R3 from stats_host (mean, total variance)
   static void fit(H& h, const CsrView<T>& A, bool defer_finish = false);
+  static void finish_small_svd(H& h, const double** sign_out);   // host half of the f32 small SVD (R11) + svd_flip
   static void finish_fit(H& h);          // host-side tail of fit(): statistics, timings (after the last wait for the device)
   static void transform(H& h, const CsrView<T>& A, T* d_out);
   static void fit_randomized(H& h);
@@ -126,7 +132,7 @@ struct Engine {
   // normaliser on a rows x ld panel; R_out (ld x ld f64 device, may be null) receives the
   // accumulated upper factor of the last CholeskyQR2.
   static void normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2,
-                        int passes_hint = 0);
+                        int passes_hint = 0, const k::PanelSource<T>* src = nullptr, const T* w = nullptr, T* vec_out = nullptr);
   static CsrView<T> view(const H::RawCsr& r) {
     CsrView<T> v;
     v.rows = r.rows; v.cols = r.cols; v.nnz = r.nnz;

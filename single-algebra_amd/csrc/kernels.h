@@ -7,6 +7,18 @@
 namespace sapca {
 namespace k {
 
+// How the producer of a panel left it: P = sum of nsplit slabs (slab sp at parts + sp * slab_stride, row stride = the panel's)
+// minus the centring term mu sv^T (mu per row, sv per column; null: none).  gram() applies it on its way through the panel
+// and writes P; materialize() only writes P.  parts may be P itself (nsplit = 1).
+template <typename T>
+struct PanelSource {
+  const T* parts = nullptr;
+  int nsplit = 0;
+  int64_t slab_stride = 0;
+  const T* mu = nullptr;
+  const T* sv = nullptr;
+};
+
 // ---- prep.hip --------------------------------------------------------------------------
 // nalgebra's usize indices -> int64 row offsets + int32 column indices; *flag |= 1 on col >= n.
 void narrow_indices(const uint64_t* ptr64, const uint64_t* idx64, int64_t m, int64_t nnz, int64_t n,
@@ -80,9 +92,11 @@ void row_stats(const CsrView<T>& A, double* sum, double* sumsq, T* minv, T* maxv
 // ---- spmm.hip --------------------------------------------------------------------------
 // Y[r][j] = sum_e val_e X[col_e][j] - cvec[j]   for j < ncols; X has leading dimension ldx
 // (multiple of 16/sizeof(T)... see spmm.hip), Y leading dimension ldy.  cvec may be null.
+// keep (nullable): a staged sweep whose tile range is split over workgroups may leave its partial slabs unsummed and describe
+// them there (nsplit > 1; the caller's next pass over Y -- gram() -- sums them); otherwise keep = {Y, 1, 0}.  Only with cvec null.
 template <typename T>
 void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, int ldy, int ncols,
-          const T* cvec, int variant, DevBuf& scratch, hipStream_t s);
+          const T* cvec, int variant, DevBuf& scratch, hipStream_t s, PanelSource<T>* keep = nullptr);
 
 // Y[r][j] = sum over the stored entries of row r of (value - shift[column]) X[column][j]   (quirk Q3 through the row kernel)
 template <typename T>
@@ -135,14 +149,14 @@ int tiled_tile_count(int64_t cols, int ldp);
 // tile geometry (panel columns held per LDS tile row) for a panel of l columns: 64, two column passes when l > 64
 int tiled_geometry(int l);
 void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
-                hipStream_t s);
+                hipStream_t s, PanelSource<float>* keep = nullptr);
 // the DPP-fed sweep in pieces of its output rows (spmm_tiled.hip): can the operator be swept so, the pieces' row bounds, one piece
 bool spmm_tiled_pieces_ok(const TiledOp& op, int npieces, int ldx);
 void spmm_tiled_piece_bounds(const TiledOp& op, int npieces, std::vector<int64_t>& bounds, hipStream_t s);
 void spmm_tiled_piece(const TiledOp& op, int piece, int npieces, int wgs, int64_t first_row, int64_t row_count, const float* X, int ldx, float* Y,
                       int ldy, int ncols, DevBuf& scratch, hipStream_t s);
 void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
-                hipStream_t s);
+                hipStream_t s, PanelSource<double>* keep = nullptr);
 
 // ---- dense.hip -------------------------------------------------------------------------
 // widest panel (n_components + n_oversamples, padded) the dense kernels take: up to 128 columns in one launch, beyond that in
@@ -151,10 +165,16 @@ constexpr int kMaxPanelWidth = 1024;
 
 // G = P^T P (ld x ld, f64, full symmetric) for a rows x ld panel with ld % 16 == 0 (ld <= 128) or ld % 64 == 0 (ld <= 1024).
 template <typename T>
-void gram(const T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s);
+void materialize(T* P, int64_t rows, int ld, const PanelSource<T>& src, hipStream_t s);
+// wsum (nullable, ld doubles): sum_r w[r] P[r][:] of the same pass (w null: ones)
+template <typename T>
+void gram(T* P, int64_t rows, int ld, double* G, DevBuf& scratch, hipStream_t s, const PanelSource<T>* src = nullptr, const T* w = nullptr,
+          double* wsum = nullptr);
 // Upper Cholesky G = R^T R on the leading l x l block, Rinv = R^{-1}; both ld x ld, zero padded.
 // *info += number of pivots that had to be regularised.
-void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s);
+// wsum / vec32 / vec64 (nullable): vec[j] = sum_i Rinv[i][j] wsum[i] -- the column sums of P R^-1 from those of P
+void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s, const double* wsum = nullptr,
+              float* vec32 = nullptr, double* vec64 = nullptr);
 
 // Eigen-decomposition of the symmetric l x l matrix G (row stride ld) on the device, one workgroup (parallel Jacobi in LDS,
 // l <= 112): M (ld x ldk, zero padded) = leading k eigenvectors in columns, each divided by sigma_j = sqrt(lambda_j), in
@@ -163,8 +183,10 @@ bool sym_eig_device_ok(int l);
 void sym_eig_device(const double* G, int l, int ld, int k, int ldk, double* M, double* sigma, int* status, hipStream_t s);
 // out[rows x ldo] = P[rows x ld] * M[ld x ldo]  (M f64, row-major, ldo % 16 == 0); out may alias P
 // when ldo == ld.
+// out_stride (0: ldo) is the row stride of `out`, out_cols (0: ldo) the number of leading columns written.
 template <typename T>
-void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, bool upper = false);
+void panel_gemm(const T* P, int64_t rows, int ld, const double* M, int ldo, T* out, hipStream_t s, bool upper = false, int out_stride = 0,
+                int out_cols = 0);
 // out[j] = sum_r w[r] P[r][j]  (w null => ones), j < ld, f64 accumulation.
 template <typename T>
 void weighted_colsum(const T* P, int64_t rows, int ld, const T* w, T* out, DevBuf& scratch, hipStream_t s);
@@ -173,8 +195,13 @@ template <typename T>
 void rank1_subtract(T* Z, int64_t rows, int ld, const T* mu, const T* svec, hipStream_t s);
 // components[r][j] = sign_r * VtT[j][r] for r < k, with sign_r making the largest-|.| entry of
 // row r positive (first index on ties): single_svdlib::randomized::svd_flip, v-based.
+// sign_out (nullable): receives the device address of the k signs (in `scratch`)
 template <typename T>
-void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s);
+void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s, const double** sign_out = nullptr);
+// out[j][c] = scale[j] * P[j][c] (scale null: copy); M[i][j] *= sign[j] for j < k
+template <typename T>
+void scale_rows(const T* P, int64_t rows, int ld, const double* scale, T* out, hipStream_t s);
+void scale_columns(double* M, int rows, int ld, int k, const double* sign, hipStream_t s);
 // W[j][r] = scale[j] * comps[r][j]  (r < k; zero for k <= r < ld); scale may be null.
 template <typename T>
 void scaled_transpose(const T* comps, int64_t n, int k, const double* scale, T* W, int ld, hipStream_t s);

@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(1024)
 spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const I* __restrict__ idx, const T* __restrict__ val, int64_t rows,
                  int64_t cols, const double* __restrict__ x, double* __restrict__ y, unsigned long long* __restrict__ ymax_bits) {
   extern __shared__ double xs[];
+  bool ybad = false;
   double ymax = 0.0;   // (lane 0 of every wave: the largest |y| it wrote, for the fixed-point scale of the scatter product that follows)
   for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) xs[i] = x[i];
   __syncthreads();
@@ -92,9 +93,11 @@ spmv_ldsx_kernel(const int64_t* __restrict__ ptr, const I* __restrict__ idx, con
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) a0 += __shfl_xor(a0, off);
     if (lane == 0) y[r] = a0;
+    ybad |= !(fabs(a0) <= 1.7976931348623157e308);   // (a non-finite y must reach the fixed-point scale: fmax would drop a nan)
     ymax = fmax(ymax, fabs(a0));
   }
-  if (ymax_bits && lane == 0) atomicMax(ymax_bits, (unsigned long long)__double_as_longlong(ymax));   // non-negative doubles order like integers
+  // non-negative doubles -- and the quiet-nan pattern above them all -- order like integers
+  if (ymax_bits && lane == 0) atomicMax(ymax_bits, ybad ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(ymax));
 }
 
 // Long x (A^T y: x has one element per sample): x is cut into slices that fit LDS and a workgroup walks its

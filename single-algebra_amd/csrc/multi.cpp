@@ -128,19 +128,45 @@ int inprocess_allreduce(void* ctx, void* buf, uint64_t count, int32_t dtype, voi
 
 }  // namespace
 
+// a member's resident shard (sapca_multi_upload_csr_*): arrays owned by the member handle
+struct Shard {
+  uint64_t row0 = 0, rows = 0, nnz = 0;
+  const int64_t* ptr = nullptr;
+  const int32_t* idx = nullptr;
+  void* val = nullptr;
+};
+
 struct sapca_multi_s {
   std::vector<sapca_handle> h;
   std::vector<int32_t> devices;
   std::vector<RankCtx> ctx;
   InProcess inproc;
   bool rccl = false;
+  bool comm_broken = false;   // a member failed under RCCL: every communicator was aborted, the next call builds new ones
+  bool connecting = false;    // inside the collective ncclCommInitRank: nothing to abort yet
   uint64_t k = 0;
   std::string err;
+  // resident shards
+  std::vector<Shard> shard;
+  uint64_t res_m = 0, res_n = 0;
+  int res_dtype = -1;   // 0 f32, 1 f64, -1 nothing uploaded
 };
 
 namespace {
 
 thread_local std::string g_multi_create_error;
+
+// A member that fails outside a collective never joins the ones its peers wait in.  In-process transport: the rendezvous
+// is abandoned.  RCCL: every member's communicators are aborted (ncclCommAbort, callable from this thread while the
+// peers' threads sit behind their streams) -- their collectives return, their next one fails at once with
+// SAPCA_ERR_COMM -- and the sapca_multi builds new communicators at its next call.
+void release_peers(sapca_multi_s* mh) {
+  mh->inproc.rv.abandon();
+  if (!mh->rccl) return;
+  mh->comm_broken = true;
+  if (mh->connecting) return;
+  for (sapca_handle h : mh->h) (void)sapca_comm_abort(h);
+}
 
 // one host thread per device; returns the first failing status (and that device's message)
 template <typename F>
@@ -148,11 +174,17 @@ sapca_status on_every_device(sapca_multi_s* mh, F&& f) {
   const int nd = (int)mh->h.size();
   std::vector<sapca_status> st((size_t)nd, SAPCA_OK);
   mh->inproc.rv.reset(nd);
+  std::mutex release_mu;
+  bool released = false;
   std::vector<std::thread> th;
   for (int i = 0; i < nd; ++i)
     th.emplace_back([&, i] {
       st[(size_t)i] = f(i);
-      if (st[(size_t)i] != SAPCA_OK) mh->inproc.rv.abandon();   // (nobody waits for a rank that has already left)
+      if (st[(size_t)i] != SAPCA_OK && nd > 1) {   // (nobody waits for a rank that has already left)
+        std::lock_guard<std::mutex> lk(release_mu);
+        if (!released) release_peers(mh);
+        released = true;
+      }
     });
   for (auto& t : th) t.join();
   // the device that failed first in its own right (not because a peer abandoned the collective) explains the failure best
@@ -163,6 +195,56 @@ sapca_status on_every_device(sapca_multi_s* mh, F&& f) {
   const char* msg = sapca_last_error(mh->h[(size_t)bad]);
   mh->err = std::string("device ") + std::to_string(mh->devices[(size_t)bad]) + " (shard " + std::to_string(bad) + "): " + (msg ? msg : "");
   return st[(size_t)bad];
+}
+
+void use_inprocess(sapca_multi_s* mh) {
+  const uint32_t nd = (uint32_t)mh->h.size();
+  mh->rccl = false;
+  mh->inproc.stage.resize(nd);
+  mh->ctx.resize(nd);
+  for (uint32_t i = 0; i < nd; ++i) {
+    mh->ctx[i].shared = &mh->inproc;
+    mh->ctx[i].rank = (int)i;
+    mh->ctx[i].nranks = (int)nd;
+    // (set_callback destroys whatever communicator the member still holds)
+    (void)sapca_comm_set_callback(mh->h[i], nd, i, &inprocess_allreduce, &mh->ctx[i]);
+  }
+}
+
+// RCCL between the members: ncclCommInitRank is collective, one thread per device enters it.  All members get their
+// communicators or none keeps one (the in-process transport takes over).
+bool connect_rccl(sapca_multi_s* mh) {
+  const uint32_t nd = (uint32_t)mh->h.size();
+  uint8_t id[128];
+  if (sapca_comm_unique_id(id) != SAPCA_OK) return false;
+  mh->rccl = true;   // (a member whose init fails aborts the others' communicators: release_peers)
+  mh->comm_broken = false;
+  mh->connecting = true;
+  const sapca_status st = on_every_device(mh, [&](int i) { return sapca_comm_init_rank(mh->h[(size_t)i], nd, (uint32_t)i, id); });
+  mh->connecting = false;
+  if (st == SAPCA_OK && !mh->comm_broken) return true;
+  mh->comm_broken = false;
+  use_inprocess(mh);
+  return false;
+}
+
+// before every sharded call: communicators that were aborted by the previous call's failure are replaced
+void ensure_comm(sapca_multi_s* mh) {
+  if (mh->h.size() > 1 && mh->rccl && mh->comm_broken) (void)connect_rccl(mh);
+}
+
+// nnz-balanced row ranges of a host CSR, one per device (even row counts if a shard would be empty)
+sapca_status shard_bounds(sapca_multi_s* mh, uint64_t m, const uint64_t* ro, std::vector<uint64_t>& bounds) {
+  const uint32_t nd = (uint32_t)mh->h.size();
+  bounds.assign((size_t)nd + 1, 0);
+  const sapca_status st = sapca_partition_rows(m, ro, nd, bounds.data());
+  if (st != SAPCA_OK) { mh->err = "row_offsets are not a CSR offset array"; return st; }
+  for (uint32_t i = 0; i < nd; ++i)
+    if (bounds[i] == bounds[i + 1]) {   // (a shard without rows: a few very long rows; even row counts then)
+      for (uint32_t j = 0; j <= nd; ++j) bounds[j] = m * j / nd;
+      break;
+    }
+  return SAPCA_OK;
 }
 
 template <typename T> struct HostAbi;
@@ -184,14 +266,11 @@ sapca_status sharded(sapca_multi_s* mh, int op, uint64_t m, uint64_t n, uint64_t
   const uint32_t nd = (uint32_t)mh->h.size();
   if (!ro || (nnz && (!ci || !v)) || (op != 0 && !out && m)) { mh->err = "null CSR array or output buffer"; return SAPCA_ERR_ARG; }
   if (m < nd) { mh->err = "fewer rows than devices"; return SAPCA_ERR_ARG; }
-  std::vector<uint64_t> bounds((size_t)nd + 1);
-  sapca_status st = sapca_partition_rows(m, ro, nd, bounds.data());
-  if (st != SAPCA_OK) { mh->err = "row_offsets are not a CSR offset array"; return st; }
-  for (uint32_t i = 0; i < nd; ++i)
-    if (bounds[i] == bounds[i + 1]) {   // (a shard without rows: a few very long rows; even row counts then)
-      for (uint32_t j = 0; j <= nd; ++j) bounds[j] = m * j / nd;
-      break;
-    }
+  ensure_comm(mh);
+  mh->res_dtype = -1;   // (the host entry points reuse the members' upload buffers: resident shards are gone)
+  std::vector<uint64_t> bounds;
+  sapca_status st = shard_bounds(mh, m, ro, bounds);
+  if (st != SAPCA_OK) return st;
   if (mh->rccl && nnz) {
     // A rank that refuses its shard (a column index out of range) would leave its peers inside an RCCL collective for good:
     // the whole matrix is checked before anyone starts.  (The in-process transport releases the peers instead.)
@@ -220,6 +299,89 @@ sapca_status sharded(sapca_multi_s* mh, int op, uint64_t m, uint64_t n, uint64_t
     if (op == 0) return HostAbi<T>::fit(h, mi, n, zi, rebased.data(), cii, vi);
     if (op == 1) return HostAbi<T>::transform(h, mi, n, zi, rebased.data(), cii, vi, oi);
     return HostAbi<T>::fit_transform(h, mi, n, zi, rebased.data(), cii, vi, oi);
+  });
+}
+
+template <typename T> struct ResidentAbi;
+template <> struct ResidentAbi<float> {
+  static constexpr int dtype = 0;
+  static sapca_status upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t z, const uint64_t* p, const uint64_t* i, const float* v, Shard& sh) {
+    float* dv = nullptr;
+    const sapca_status st = sapca_upload_csr_f32(h, m, n, z, p, i, v, &sh.ptr, &sh.idx, &dv);
+    sh.val = dv;
+    return st;
+  }
+  static sapca_status fit(sapca_handle h, uint64_t n, const Shard& sh) { return sapca_fit_csr_device_f32(h, sh.rows, n, sh.nnz, sh.ptr, sh.idx, static_cast<const float*>(sh.val)); }
+  static sapca_status transform(sapca_handle h, uint64_t n, const Shard& sh, float* o) { return sapca_transform_csr_device_to_host_f32(h, sh.rows, n, sh.nnz, sh.ptr, sh.idx, static_cast<const float*>(sh.val), o); }
+  static sapca_status fit_transform(sapca_handle h, uint64_t n, const Shard& sh, float* o) { return sapca_fit_transform_csr_device_to_host_f32(h, sh.rows, n, sh.nnz, sh.ptr, sh.idx, static_cast<const float*>(sh.val), o); }
+};
+template <> struct ResidentAbi<double> {
+  static constexpr int dtype = 1;
+  static sapca_status upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t z, const uint64_t* p, const uint64_t* i, const double* v, Shard& sh) {
+    double* dv = nullptr;
+    const sapca_status st = sapca_upload_csr_f64(h, m, n, z, p, i, v, &sh.ptr, &sh.idx, &dv);
+    sh.val = dv;
+    return st;
+  }
+  static sapca_status fit(sapca_handle h, uint64_t n, const Shard& sh) { return sapca_fit_csr_device_f64(h, sh.rows, n, sh.nnz, sh.ptr, sh.idx, static_cast<const double*>(sh.val)); }
+  static sapca_status transform(sapca_handle h, uint64_t n, const Shard& sh, double* o) { return sapca_transform_csr_device_to_host_f64(h, sh.rows, n, sh.nnz, sh.ptr, sh.idx, static_cast<const double*>(sh.val), o); }
+  static sapca_status fit_transform(sapca_handle h, uint64_t n, const Shard& sh, double* o) { return sapca_fit_transform_csr_device_to_host_f64(h, sh.rows, n, sh.nnz, sh.ptr, sh.idx, static_cast<const double*>(sh.val), o); }
+};
+
+// every shard to its device, side by side (one host thread per device: the uploads share nothing but the host's DRAM)
+template <typename T>
+sapca_status upload_shards(sapca_multi_s* mh, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci, const T* v) {
+  if (!mh) return SAPCA_ERR_ARG;
+  const uint32_t nd = (uint32_t)mh->h.size();
+  mh->res_dtype = -1;
+  if (!ro || (nnz && (!ci || !v))) { mh->err = "null CSR array"; return SAPCA_ERR_ARG; }
+  if (m < nd) { mh->err = "fewer rows than devices"; return SAPCA_ERR_ARG; }
+  std::vector<uint64_t> bounds;
+  sapca_status st = shard_bounds(mh, m, ro, bounds);
+  if (st != SAPCA_OK) return st;
+  mh->shard.assign(nd, Shard());
+  // (no collective in here: a member that fails -- a column index out of range, no memory -- leaves nobody waiting; the
+  //  rendezvous / communicators are not touched)
+  std::vector<sapca_status> sts(nd, SAPCA_OK);
+  std::vector<std::thread> th;
+  for (uint32_t i = 0; i < nd; ++i)
+    th.emplace_back([&, i] {
+      const uint64_t r0 = bounds[i], r1 = bounds[i + 1], e0 = ro[r0];
+      std::vector<uint64_t> rebased((size_t)(r1 - r0) + 1);
+      for (uint64_t r = r0; r <= r1; ++r) rebased[(size_t)(r - r0)] = ro[r] - e0;
+      Shard& sh = mh->shard[i];
+      sh.row0 = r0; sh.rows = r1 - r0; sh.nnz = ro[r1] - e0;
+      sts[i] = ResidentAbi<T>::upload(mh->h[i], sh.rows, n, sh.nnz, rebased.data(), ci ? ci + e0 : nullptr, v ? v + e0 : nullptr, sh);
+    });
+  for (auto& t : th) t.join();
+  for (uint32_t i = 0; i < nd; ++i)
+    if (sts[i] != SAPCA_OK) {
+      const char* msg = sapca_last_error(mh->h[i]);
+      mh->err = std::string("device ") + std::to_string(mh->devices[i]) + " (shard " + std::to_string(i) + "): " + (msg ? msg : "");
+      return sts[i];
+    }
+  mh->res_m = m; mh->res_n = n; mh->res_dtype = ResidentAbi<T>::dtype;
+  mh->err.clear();
+  return SAPCA_OK;
+}
+
+// op: 0 fit, 1 transform, 2 fit_transform on the resident shards
+template <typename T>
+sapca_status resident(sapca_multi_s* mh, int op, T* out) {
+  if (!mh) return SAPCA_ERR_ARG;
+  if (mh->res_dtype != ResidentAbi<T>::dtype) {
+    mh->err = mh->res_dtype < 0 ? "no resident matrix: call sapca_multi_upload_csr_* first" : "the resident matrix has the other value type";
+    return SAPCA_ERR_ARG;
+  }
+  if (op != 0 && !out) { mh->err = "null output buffer"; return SAPCA_ERR_ARG; }
+  ensure_comm(mh);
+  return on_every_device(mh, [&](int i) {
+    const Shard& sh = mh->shard[(size_t)i];
+    T* oi = out ? out + sh.row0 * mh->k : nullptr;
+    sapca_handle h = mh->h[(size_t)i];
+    if (op == 0) return ResidentAbi<T>::fit(h, mh->res_n, sh);
+    if (op == 1) return ResidentAbi<T>::transform(h, mh->res_n, sh, oi);
+    return ResidentAbi<T>::fit_transform(h, mh->res_n, sh, oi);
   });
 }
 
@@ -255,25 +417,8 @@ sapca_status sapca_multi_create(const sapca_options* opts, const int32_t* device
   }
   if (n_devices > 1) {
     const std::set<int32_t> distinct(mh->devices.begin(), mh->devices.end());
-    bool want_rccl = distinct.size() == n_devices && sapca_comm_rccl_available() != 0 && getenv("SAPCA_MULTI_INPROCESS") == nullptr;
-    uint8_t id[128];
-    if (want_rccl && sapca_comm_unique_id(id) != SAPCA_OK) want_rccl = false;
-    if (want_rccl) {
-      // ncclCommInitRank is collective: one thread per device enters it (every member either gets its communicator or all fall back)
-      const sapca_status st = on_every_device(mh, [&](int i) { return sapca_comm_init_rank(mh->h[(size_t)i], n_devices, (uint32_t)i, id); });
-      mh->rccl = st == SAPCA_OK;
-    }
-    if (!mh->rccl) {
-      mh->inproc.stage.resize(n_devices);
-      mh->ctx.resize(n_devices);
-      for (uint32_t i = 0; i < n_devices; ++i) {
-        mh->ctx[i].shared = &mh->inproc;
-        mh->ctx[i].rank = (int)i;
-        mh->ctx[i].nranks = (int)n_devices;
-        const sapca_status st = sapca_comm_set_callback(mh->h[i], n_devices, i, &inprocess_allreduce, &mh->ctx[i]);
-        if (st != SAPCA_OK) return fail(st, sapca_last_error(mh->h[i]));
-      }
-    }
+    const bool want_rccl = distinct.size() == n_devices && sapca_comm_rccl_available() != 0 && getenv("SAPCA_MULTI_INPROCESS") == nullptr;
+    if (!want_rccl || !connect_rccl(mh)) use_inprocess(mh);
   }
   *out = mh;
   return SAPCA_OK;
@@ -317,6 +462,34 @@ sapca_status sapca_multi_fit_transform_csr_f32(sapca_multi mh, uint64_t m, uint6
 }
 sapca_status sapca_multi_fit_transform_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci, const double* v, double* out) {
   return sharded<double>(mh, 2, m, n, nnz, ro, ci, v, out);
+}
+
+sapca_status sapca_multi_upload_csr_f32(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci, const float* v) {
+  return upload_shards<float>(mh, m, n, nnz, ro, ci, v);
+}
+sapca_status sapca_multi_upload_csr_f64(sapca_multi mh, uint64_t m, uint64_t n, uint64_t nnz, const uint64_t* ro, const uint64_t* ci, const double* v) {
+  return upload_shards<double>(mh, m, n, nnz, ro, ci, v);
+}
+sapca_status sapca_multi_fit_resident(sapca_multi mh) {
+  if (!mh) return SAPCA_ERR_ARG;
+  return mh->res_dtype == 1 ? resident<double>(mh, 0, nullptr) : resident<float>(mh, 0, nullptr);
+}
+sapca_status sapca_multi_transform_resident_f32(sapca_multi mh, float* out) { return resident<float>(mh, 1, out); }
+sapca_status sapca_multi_transform_resident_f64(sapca_multi mh, double* out) { return resident<double>(mh, 1, out); }
+sapca_status sapca_multi_fit_transform_resident_f32(sapca_multi mh, float* out) { return resident<float>(mh, 2, out); }
+sapca_status sapca_multi_fit_transform_resident_f64(sapca_multi mh, double* out) { return resident<double>(mh, 2, out); }
+
+sapca_status sapca_multi_resident_shard(sapca_multi mh, uint32_t i, uint64_t* first_row, uint64_t* rows, uint64_t* nnz,
+                                        const int64_t** d_row_offsets, const int32_t** d_col_indices, void** d_values) {
+  if (!mh || mh->res_dtype < 0 || i >= mh->shard.size()) return SAPCA_ERR_ARG;
+  const Shard& sh = mh->shard[i];
+  if (first_row) *first_row = sh.row0;
+  if (rows) *rows = sh.rows;
+  if (nnz) *nnz = sh.nnz;
+  if (d_row_offsets) *d_row_offsets = sh.ptr;
+  if (d_col_indices) *d_col_indices = sh.idx;
+  if (d_values) *d_values = sh.val;
+  return SAPCA_OK;
 }
 
 }  // extern "C"

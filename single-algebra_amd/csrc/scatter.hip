@@ -31,7 +31,9 @@ __device__ inline double fixed_scale(double total) {
   if (!(total > 0.0)) return 0.0;
   int e;
   (void)frexp(total, &e);   // total < 2^e
-  return ldexp(1.0, 61 - e);
+  // (operands of tiny magnitude: 2^(61 - e) leaves the double range below total = 2^-962; the largest finite power of two keeps
+  //  every product representable -- the sums then carry fewer than 61 bits, not garbage -- and 1 / scale finite)
+  return ldexp(1.0, min(61 - e, 1023));
 }
 
 __device__ inline double bits_to_double(unsigned long long b) { return __longlong_as_double((long long)b); }
@@ -123,8 +125,13 @@ spmvt_reduce_kernel(const long long* __restrict__ part, int nparts, int64_t rows
 __global__ void __launch_bounds__(256)
 vecmax_kernel(const double* __restrict__ y, int64_t len, unsigned long long* __restrict__ out_bits) {
   double m = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, fabs(y[i]));
-  unsigned long long b = (unsigned long long)__double_as_longlong(m);
+  bool bad = false;   // (fmax drops a nan: a non-finite y must reach the scale, as it reaches the sums of the floating-point route)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const double a = fabs(y[i]);
+    bad |= !(a <= 1.7976931348623157e308);
+    m = fmax(m, a);
+  }
+  unsigned long long b = bad ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(m);
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) b = max(b, (unsigned long long)__shfl_xor((long long)b, off));
   if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(out_bits, b);

@@ -248,8 +248,9 @@ void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, i
 
 template <typename T>
 void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, int ldy, int ncols, const T* cvec,
-          int variant, DevBuf& scratch, hipStream_t s) {
+          int variant, DevBuf& scratch, hipStream_t s, PanelSource<T>* keep) {
   constexpr int VEC = Vec<T>::N;
+  if (keep) { keep->parts = Y; keep->nsplit = 1; keep->slab_stride = 0; }
   SAPCA_CHECK(ldx % VEC == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, SAPCA_ERR_ARG,
               "spmm: panel must be 16-byte aligned with a leading dimension that is a multiple of 16 bytes");
   SAPCA_CHECK(ncols <= ldx && ncols <= ldy, SAPCA_ERR_ARG, "spmm: ncols exceeds a leading dimension");
@@ -259,7 +260,7 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
     const bool geom_ok = tiled && tiled->elem == 4 && (tiled->ldp == ldx || (tiled->fmt == 1 && tiled->ldp == 64 && ldx % 64 == 0));
     if (variant != 1 && tiled && tiled->valid && geom_ok && tiled->rows == A.rows && tiled->cols == A.cols) {
       spmm_tiled(*tiled, reinterpret_cast<const float*>(X), ldx, reinterpret_cast<float*>(Y), ldy, ncols,
-                 reinterpret_cast<const float*>(cvec), scratch, s);
+                 reinterpret_cast<const float*>(cvec), scratch, s, reinterpret_cast<PanelSource<float>*>(keep));
       return;
     }
   } else {
@@ -267,7 +268,7 @@ void spmm(const CsrView<T>& A, const TiledOp* tiled, const T* X, int ldx, T* Y, 
     if (variant != 1 && tiled && tiled->valid && tiled->elem == 8 && ldx % tiled->ldp == 0 && tiled->rows == A.rows &&
         tiled->cols == A.cols) {
       spmm_tiled(*tiled, reinterpret_cast<const double*>(X), ldx, reinterpret_cast<double*>(Y), ldy, ncols,
-                 reinterpret_cast<const double*>(cvec), scratch, s);
+                 reinterpret_cast<const double*>(cvec), scratch, s, reinterpret_cast<PanelSource<double>*>(keep));
       return;
     }
   }
@@ -296,8 +297,8 @@ void spmm_rows_shifted(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, 
 template void spmm_rows_shifted<float>(const CsrView<float>&, const float*, int, float*, int, int, const float*, hipStream_t);
 template void spmm_rows_shifted<double>(const CsrView<double>&, const double*, int, double*, int, int, const double*, hipStream_t);
 
-template void spmm<float>(const CsrView<float>&, const TiledOp*, const float*, int, float*, int, int, const float*, int, DevBuf&, hipStream_t);
-template void spmm<double>(const CsrView<double>&, const TiledOp*, const double*, int, double*, int, int, const double*, int, DevBuf&, hipStream_t);
+template void spmm<float>(const CsrView<float>&, const TiledOp*, const float*, int, float*, int, int, const float*, int, DevBuf&, hipStream_t, PanelSource<float>*);
+template void spmm<double>(const CsrView<double>&, const TiledOp*, const double*, int, double*, int, int, const double*, int, DevBuf&, hipStream_t, PanelSource<double>*);
 
 }  // namespace k
 }  // namespace sapca

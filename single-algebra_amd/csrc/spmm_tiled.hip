@@ -1491,7 +1491,9 @@ constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave o
 // row's indices for the histogram anyway.
 __global__ void __launch_bounds__(ATD_HIST_THREADS_WIDE)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
-                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, int64_t* __restrict__ bnd) {
+                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, int64_t* __restrict__ bnd, int64_t* __restrict__ disorder) {
+  // disorder: set when a row's entries leave the order the run ends rely on (a block after a later block: the caller handed
+  // over rows whose columns do not ascend) -- the host then takes the bucket route, which maps every column through a table
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
   const int t = blockIdx.x;
   const int nw = (int)(n2 / 2);
@@ -1527,6 +1529,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
           const int prev = lane == 0 ? lastb : up;
           if (valid && b != prev)
             for (int j = prev + 1; j <= b; ++j) bnd_row[j] = eb + u * WAVE;
+          if (valid && b < prev) *disorder = 1;   // (rare, benign race: every writer stores the same value)
           lastb = __builtin_amdgcn_readlane(b, __builtin_popcountll(valids) - 1);
         }
       }
@@ -2063,6 +2066,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // page-locked staging of this builder: [0] slots of the natural quads, [1..2] largest chunk | total, then the block table
   int64_t* pinned = static_cast<int64_t*>(buf.host.ensure((size_t)(8 + 65536 + 2) * sizeof(int64_t)));
   bool speculate = false;
+  bool rows_in_disorder = false;   // (bucket route: the source's rows were found unsorted by the histogram pass)
   if (sort_rows && getenv("SAPCA_ROWSORT_ALWAYS") == nullptr) {
     // homogeneous rows pad little in their natural order: skip the sort (0.2 ms per operator at C2) unless the
     // natural quads would hold 10 % more slots than entries.  The count comes back with the chunk sizes below -- the
@@ -2167,8 +2171,9 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     int64_t* d_max = buf.misc.as<int64_t>(8);
     launch_small_scan(d_chunk, d_raw, nchunks, d_max, s);
     int64_t* host = pinned + 1;
-    SAPCA_HIP(hipMemcpyAsync(host, d_max, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SAPCA_HIP(hipMemcpyAsync(host, d_max, (direct ? 7 : 2) * sizeof(int64_t), hipMemcpyDeviceToHost, s));   // (direct: + the histogram's disorder flag)
     SAPCA_HIP(hipStreamSynchronize(s));  // blk goes out of scope; sizes needed on the host
+    if (direct) rows_in_disorder = host[6] != 0;
     if (speculate) {
       speculate = false;
       if ((double)(unsigned long long)pinned[0] > 1.10 * (double)S.nnz) {   // the natural quads pad too much after all: sort, count again
@@ -2249,7 +2254,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     const CsrView<float>& A = *direct->A;
     const size_t scan_bytes = 0;   // (d_raw was scanned together with the chunk sizes)
     // SAPCA_AT_BUCKETS=1: the bucket route also where the gather fill applies (A/B runs; the two write the same bytes)
-    const bool gather = direct->bnd != nullptr && d_perm == nullptr && nrb == direct->nrb_nat && getenv("SAPCA_AT_BUCKETS") == nullptr;
+    // (rows of A whose columns do not ascend -- include/sapca.h promises wrong numbers for them, not stray accesses: the run
+    //  ends the histogram recorded are meaningless then, the bucket route needs none)
+    const bool gather = direct->bnd != nullptr && d_perm == nullptr && nrb == direct->nrb_nat && !rows_in_disorder &&
+                        getenv("SAPCA_AT_BUCKETS") == nullptr;
     const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = gather ? 0 : round_up((size_t)A.nnz * sizeof(uint2), 256);
     const size_t a_part = direct->stats ? round_up((size_t)nct * op_rows * sizeof(double), 256) : 0;
     const size_t a_scan = round_up(scan_bytes + 256, 256);
@@ -2368,8 +2376,10 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   std::vector<int32_t> blk_nat;
   float blk_scale = 0.f;
   if (bnd) float_blocks(n, nrb_nat, blk_nat, blk_scale);
+  int64_t* d_disorder = buf.misc.as<int64_t>(8) + 6;   // (read back with the builder's one host exchange)
+  SAPCA_HIP(hipMemsetAsync(d_disorder, 0, sizeof(int64_t), s));
   hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 52 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),   // (above 52 KiB two workgroups share a CU: sixteen waves each)
-                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, blk_scale, (int)nrb_nat, bnd);
+                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, blk_scale, (int)nrb_nat, bnd, d_disorder);
   hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
   launch_small_scan(at_ptr, nullptr, n, nullptr, s);
   SAPCA_HIP(hipGetLastError());
@@ -2395,7 +2405,7 @@ int tiled_tile_count(int64_t cols, int ldp) {
 }
 
 void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, int ncols, const float* cvec, DevBuf& scratch,
-                hipStream_t s) {
+                hipStream_t s, PanelSource<float>* keep) {
   SAPCA_CHECK(op.valid && op.elem == 4, SAPCA_ERR_ARG, "tiled sweep: operator not built");
   SAPCA_CHECK(ldx == op.ldp || (op.fmt == 1 && op.ldp == 64 && ldx % 64 == 0), SAPCA_ERR_ARG,
               "tiled sweep: panel leading dimension does not match the operator's tile geometry");
@@ -2444,6 +2454,12 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
     }
     if (op.nsplit > 1) {
       const int64_t total = op.rows * (int64_t)op.ldp;
+      if (keep && passes == 1 && !cv && ldy == op.ldp && ncp == op.ldp) {   // the caller's next pass over Y sums the slabs
+        keep->parts = part;
+        keep->nsplit = op.nsplit;
+        keep->slab_stride = total;
+        break;
+      }
       hipLaunchKernelGGL(split_reduce_kernel<float>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
                          op.ldp, ncp, cv, Y + c0, ldy);
     }
@@ -2492,7 +2508,7 @@ void spmm_tiled_piece(const TiledOp& op, int piece, int npieces, int wgs, int64_
 }
 
 void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy, int ncols, const double* cvec, DevBuf& scratch,
-                hipStream_t s) {
+                hipStream_t s, PanelSource<double>* keep) {
   SAPCA_CHECK(op.valid && op.elem == 8 && op.fmt == 1, SAPCA_ERR_ARG, "tiled sweep: no f64 operator built");
   SAPCA_CHECK(ldx >= op.ldp && ldx % op.ldp == 0, SAPCA_ERR_ARG,
               "tiled sweep: panel leading dimension does not match the operator's tile geometry");
@@ -2516,6 +2532,12 @@ void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy,
     else launch_quad_f64<Q_TILE_BYTES>(op, Xp, ldx, out, ldo, nc, cv, s);
     if (op.nsplit > 1) {
       const int64_t total = op.rows * (int64_t)op.ldp;
+      if (keep && passes == 1 && !cv && ldy == op.ldp && ncp == op.ldp) {   // the caller's next pass over Y sums the slabs
+        keep->parts = part;
+        keep->nsplit = op.nsplit;
+        keep->slab_stride = total;
+        break;
+      }
       hipLaunchKernelGGL(split_reduce_kernel<double>, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, part, op.nsplit, op.rows,
                          op.ldp, ncp, cv, Y + c0, ldy);
     }

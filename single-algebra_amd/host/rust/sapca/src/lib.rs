@@ -9,7 +9,12 @@
 //! Here T is bounded by the sealed trait `SapcaFloat`, implemented for exactly those two: it carries the
 //! `_f32` / `_f64` entry points of include/sapca.h as associated functions.
 //!
-//! UNTESTED SOURCE: written against include/sapca.h (ABI version 3), never compiled (no rustc in the build image).
+//! `build()` is infallible, as in the reference (sparse/mod.rs:470-483): a builder only records its parameters; the GPU
+//! handle is created by the first `fit` / `fit_transform`, whose `Result` carries a creation failure.  The README's
+//! examples (README.md:48-96) compile against this crate with the `use` paths changed from `single_algebra::` to
+//! `sapca::` (the module tree `dimred::pca::{sparse, sparse_masked}` is mirrored below).
+//!
+//! UNTESTED SOURCE: written against include/sapca.h, never compiled (no rustc in the build image).
 use anyhow::{anyhow, Result};
 use nalgebra_sparse::CsrMatrix;
 use ndarray::{Array1, Array2};
@@ -167,103 +172,134 @@ fn create(n_components: usize, alpha: f64, tolerance: f64, seed: u32, center: bo
     Ok(h)
 }
 
+/// What a builder records (sparse/mod.rs:37-46: the estimator's own fields); the handle is made from it on first use.
+#[derive(Clone)]
+struct Config {
+    n_components: usize, alpha: f64, tolerance: f64, random_seed: u32, center: bool, verbose: bool,
+    svdmethod: SVDMethod, mask: Option<Vec<bool>>, devices: Vec<i32>,
+}
+impl Config {
+    fn create(&self) -> Result<Handle> {
+        create(self.n_components, self.alpha, self.tolerance, self.random_seed, self.center, self.verbose, self.svdmethod,
+               self.mask.as_deref(), &self.devices)
+    }
+}
+
 /// SparsePCA<T> (sparse/mod.rs:33-359)
-pub struct SparsePCA<T: SapcaFloat> { h: Handle, n_components: usize, _t: PhantomData<T> }
+pub struct SparsePCA<T: SapcaFloat> { cfg: Config, h: Option<Handle>, _t: PhantomData<T> }
 
 impl<T: SapcaFloat> SparsePCA<T> {
+    /// sparse/mod.rs:63-84 (same argument order, `tollerance` spelled as there)
+    pub fn new(n_components: usize, alpha: T, tollerance: Option<T>, random_seed: Option<u32>, center: bool, verbose: bool,
+               svdmethod: SVDMethod) -> Self {
+        Self::from_config(Config { n_components, alpha: alpha.to_f64(), tolerance: tollerance.map(|t| t.to_f64()).unwrap_or(1e-6),
+                                   random_seed: random_seed.unwrap_or(42), center, verbose, svdmethod, mask: None, devices: Vec::new() })
+    }
+    fn from_config(cfg: Config) -> Self { Self { cfg, h: None, _t: PhantomData } }
+    /// the handle, created on the first fit (a creation failure -- no GPU, no memory -- surfaces in that call's Result)
+    fn handle_mut(&mut self) -> Result<&Handle> {
+        if self.h.is_none() { self.h = Some(self.cfg.create()?); }
+        Ok(self.h.as_ref().unwrap())
+    }
+    /// for the `&self` methods: no handle yet means nothing was fitted -- the reference's own messages
+    fn handle(&self, msg: &'static str) -> Result<&Handle> { self.h.as_ref().ok_or_else(|| anyhow!(msg)) }
     /// sparse/mod.rs:102-242
     pub fn fit(&mut self, x: &CsrMatrix<T>) -> Result<&mut Self> {
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
-        if !self.h.1.is_null() {
-            check_multi(self.h.1, unsafe {
-                T::multi_fit(self.h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+        let h = self.handle_mut()?;
+        if !h.1.is_null() {
+            check_multi(h.1, unsafe {
+                T::multi_fit(h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                              ci.as_ptr() as *const u64, v.as_ptr())
             })?;
             return Ok(self);
         }
-        check(self.h.0, unsafe {
-            T::fit(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+        check(h.0, unsafe {
+            T::fit(h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                    ci.as_ptr() as *const u64, v.as_ptr())
         })?;
         Ok(self)
     }
     /// sparse/mod.rs:255-285 (the count-weighted projection as written there is the default; see include/sapca.h)
     pub fn transform(&self, x: &CsrMatrix<T>) -> Result<Array2<T>> {
-        let mut out = Array2::<T>::zeros((x.nrows(), self.n_components));
+        let h = self.handle("Must be fitted before transform!")?;   // sparse/mod.rs:259,263
+        let mut out = Array2::<T>::zeros((x.nrows(), self.cfg.n_components));
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
-        if !self.h.1.is_null() {
-            check_multi(self.h.1, unsafe {
-                T::multi_transform(self.h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+        if !h.1.is_null() {
+            check_multi(h.1, unsafe {
+                T::multi_transform(h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                                    ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
             })?;
             return Ok(out);
         }
-        check(self.h.0, unsafe {
-            T::transform(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+        check(h.0, unsafe {
+            T::transform(h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                          ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
         })?;
         Ok(out)
     }
     /// sparse/mod.rs:355-358
     pub fn fit_transform(&mut self, x: &CsrMatrix<T>) -> Result<Array2<T>> {
-        let mut out = Array2::<T>::zeros((x.nrows(), self.n_components));
+        let mut out = Array2::<T>::zeros((x.nrows(), self.cfg.n_components));
         let (ro, ci, v) = (x.row_offsets(), x.col_indices(), x.values());
-        if !self.h.1.is_null() {
-            check_multi(self.h.1, unsafe {
-                T::multi_fit_transform(self.h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+        let h = self.handle_mut()?;
+        if !h.1.is_null() {
+            check_multi(h.1, unsafe {
+                T::multi_fit_transform(h.1, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                                        ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
             })?;
             return Ok(out);
         }
-        check(self.h.0, unsafe {
-            T::fit_transform(self.h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
+        check(h.0, unsafe {
+            T::fit_transform(h.0, x.nrows() as u64, x.ncols() as u64, v.len() as u64, ro.as_ptr() as *const u64,
                              ci.as_ptr() as *const u64, v.as_ptr(), out.as_mut_ptr())
         })?;
         Ok(out)
     }
-    fn dims(&self) -> Result<(usize, usize, usize)> {
+    fn dims(&self) -> Result<(ffi::sapca_handle, usize, usize, usize)> {
+        let h = self.handle("Model must be fitted first!")?.0;   // sparse/mod.rs:299,316
         let (mut k, mut nu, mut nc) = (0u64, 0u64, 0u64);
-        check(self.h.0, unsafe { ffi::sapca_get_dims(self.h.0, &mut k, &mut nu, &mut nc) })?;
-        Ok((k as usize, nu as usize, nc as usize))
+        check(h, unsafe { ffi::sapca_get_dims(h, &mut k, &mut nu, &mut nc) })?;
+        Ok((h, k as usize, nu as usize, nc as usize))
     }
     /// sparse/mod.rs:295-302
     pub fn feature_importances(&self) -> Result<Array2<T>> {
-        let (k, nu, _) = self.dims()?;
+        let (h, k, nu, _) = self.dims()?;
         let mut out = Array2::<T>::zeros((k, nu));
-        check(self.h.0, unsafe { T::feature_importances(self.h.0, out.as_mut_ptr(), k * nu) })?;
+        check(h, unsafe { T::feature_importances(h, out.as_mut_ptr(), k * nu) })?;
         Ok(out)
     }
     /// sparse/mod.rs:312-322
     pub fn explained_variance_ratio(&self) -> Result<Array1<T>> {
-        let (k, _, _) = self.dims()?;
+        let (h, k, _, _) = self.dims()?;
         let mut out = Array1::<T>::zeros(k);
-        check(self.h.0, unsafe { T::explained_variance_ratio(self.h.0, out.as_mut_ptr(), k) })?;
+        check(h, unsafe { T::explained_variance_ratio(h, out.as_mut_ptr(), k) })?;
         Ok(out)
     }
     /// sparse/mod.rs:333-343
     pub fn cumulative_explained_variance_ratio(&self) -> Result<Array1<T>> {
-        let (k, _, _) = self.dims()?;
+        let (h, k, _, _) = self.dims()?;
         let mut out = Array1::<T>::zeros(k);
-        check(self.h.0, unsafe { T::cumulative_explained_variance_ratio(self.h.0, out.as_mut_ptr(), k) })?;
+        check(h, unsafe { T::cumulative_explained_variance_ratio(h, out.as_mut_ptr(), k) })?;
         Ok(out)
     }
     /// The fields the reference keeps private (sparse/mod.rs:41-43), for callers that need them.
     pub fn components(&self) -> Result<Array2<T>> {
-        let (k, nu, _) = self.dims()?;
+        let (h, k, nu, _) = self.dims()?;
         let mut out = Array2::<T>::zeros((k, nu));
-        check(self.h.0, unsafe { T::components(self.h.0, out.as_mut_ptr(), k * nu) })?;
+        check(h, unsafe { T::components(h, out.as_mut_ptr(), k * nu) })?;
         Ok(out)
     }
     pub fn explained_variance(&self) -> Result<Array1<T>> {
-        let (k, _, _) = self.dims()?;
+        let (h, k, _, _) = self.dims()?;
         let mut out = Array1::<T>::zeros(k);
-        check(self.h.0, unsafe { T::explained_variance(self.h.0, out.as_mut_ptr(), k) })?;
+        check(h, unsafe { T::explained_variance(h, out.as_mut_ptr(), k) })?;
         Ok(out)
     }
     pub fn mean(&self) -> Result<Array1<T>> {
-        let (_, _, nc) = self.dims()?;
+        let (h, _, _, nc) = self.dims()?;
         let mut out = Array1::<T>::zeros(nc);
-        check(self.h.0, unsafe { T::mean(self.h.0, out.as_mut_ptr(), nc) })?;
+        check(h, unsafe { T::mean(h, out.as_mut_ptr(), nc) })?;
         Ok(out)
     }
 }
@@ -292,12 +328,13 @@ impl<T: SapcaFloat> SparsePCABuilder<T> {
     /// the rows of every matrix passed to fit / transform / fit_transform are range-partitioned over them inside the
     /// library (include/sapca.h, sapca_multi_*), the call itself unchanged.
     pub fn devices(mut self, d: Vec<i32>) -> Self { self.devices = d; self }
-    /// The reference's `build()` is infallible; creating the GPU handle is not, hence the Result.
-    pub fn build(self) -> Result<SparsePCA<T>> {
-        let h = create(self.n_components, self.alpha, self.tolerance, self.random_seed.unwrap_or(42),
-                       self.center, self.verbose, self.svdmethod, None, &self.devices)?;
-        Ok(SparsePCA { h, n_components: self.n_components, _t: PhantomData })
+    fn config(&self, mask: Option<Vec<bool>>) -> Config {
+        Config { n_components: self.n_components, alpha: self.alpha, tolerance: self.tolerance,
+                 random_seed: self.random_seed.unwrap_or(42), center: self.center, verbose: self.verbose,
+                 svdmethod: self.svdmethod, mask, devices: self.devices.clone() }
     }
+    /// sparse/mod.rs:470-483: infallible, records the parameters (the handle is created by the first fit)
+    pub fn build(self) -> SparsePCA<T> { SparsePCA::from_config(self.config(None)) }
 }
 
 /// MaskedSparsePCA<T> (sparse_masked/mod.rs:179-620): same calls on a handle that carries the mask.
@@ -305,6 +342,15 @@ impl<T: SapcaFloat> SparsePCABuilder<T> {
 /// treats an empty mask as "no mask", so that check lives here.
 pub struct MaskedSparsePCA<T: SapcaFloat> { inner: SparsePCA<T>, mask_len: usize }
 impl<T: SapcaFloat> MaskedSparsePCA<T> {
+    /// sparse_masked/mod.rs:214-237 (same argument order)
+    pub fn new(n_components: usize, alpha: T, tollerance: Option<T>, random_seed: Option<u32>, mask: Vec<bool>, center: bool,
+               verbose: bool, svd_method: SVDMethod) -> Self {
+        let mask_len = mask.len();
+        let cfg = Config { n_components, alpha: alpha.to_f64(), tolerance: tollerance.map(|t| t.to_f64()).unwrap_or(1e-6),
+                           random_seed: random_seed.unwrap_or(42), center, verbose, svdmethod: svd_method, mask: Some(mask),
+                           devices: Vec::new() };
+        Self { inner: SparsePCA::from_config(cfg), mask_len }
+    }
     fn check_mask(&self, x: &CsrMatrix<T>) -> Result<()> {
         if x.ncols() != self.mask_len {
             return Err(anyhow!("The mask vector length and the number of features (columns) have to be the same!"));
@@ -312,6 +358,7 @@ impl<T: SapcaFloat> MaskedSparsePCA<T> {
         Ok(())
     }
     pub fn fit(&mut self, x: &CsrMatrix<T>) -> Result<&mut Self> { self.check_mask(x)?; self.inner.fit(x)?; Ok(self) }
+    /// sparse_masked/mod.rs:438-546: the mask-length check comes first (:440-444), then "Must be fitted before transform!"
     pub fn transform(&self, x: &CsrMatrix<T>) -> Result<Array2<T>> { self.check_mask(x)?; self.inner.transform(x) }
     pub fn fit_transform(&mut self, x: &CsrMatrix<T>) -> Result<Array2<T>> { self.check_mask(x)?; self.inner.fit_transform(x) }
     pub fn feature_importances(&self) -> Result<Array2<T>> { self.inner.feature_importances() }
@@ -319,12 +366,10 @@ impl<T: SapcaFloat> MaskedSparsePCA<T> {
     pub fn cumulative_explained_variance_ratio(&self) -> Result<Array1<T>> { self.inner.cumulative_explained_variance_ratio() }
     /// `cols_to_use` and the original -> masked map of sparse_masked/mod.rs:264-271, :462-466 (exact integers)
     pub fn mask_index_maps(&self) -> Result<(Vec<usize>, Vec<i64>)> {
-        let (_, nu, nc) = self.inner.dims()?;
+        let (h, _, nu, nc) = self.inner.dims()?;
         let mut cols = vec![0u64; nu.max(1)];
         let mut o2m = vec![0i64; nc.max(1)];
-        check(self.inner.h.0, unsafe {
-            ffi::sapca_get_mask_index_maps(self.inner.h.0, cols.as_mut_ptr(), cols.len(), o2m.as_mut_ptr(), o2m.len())
-        })?;
+        check(h, unsafe { ffi::sapca_get_mask_index_maps(h, cols.as_mut_ptr(), cols.len(), o2m.as_mut_ptr(), o2m.len()) })?;
         cols.truncate(nu);
         o2m.truncate(nc);
         Ok((cols.into_iter().map(|c| c as usize).collect(), o2m))
@@ -333,8 +378,11 @@ impl<T: SapcaFloat> MaskedSparsePCA<T> {
 
 /// MaskedSparsePCABuilder<T> (sparse_masked/mod.rs:37-160)
 pub struct MaskedSparsePCABuilder<T: SapcaFloat> { base: SparsePCABuilder<T>, mask: Vec<bool> }
+impl<T: SapcaFloat> Default for MaskedSparsePCABuilder<T> {
+    fn default() -> Self { Self { base: SparsePCABuilder::default(), mask: Vec::new() } }
+}
 impl<T: SapcaFloat> MaskedSparsePCABuilder<T> {
-    pub fn new() -> Self { Self { base: SparsePCABuilder::default(), mask: Vec::new() } }
+    pub fn new() -> Self { Self::default() }
     pub fn n_components(mut self, n: usize) -> Self { self.base = self.base.n_components(n); self }
     pub fn alpha(mut self, a: T) -> Self { self.base = self.base.alpha(a); self }
     pub fn tolerance(mut self, t: T) -> Self { self.base = self.base.tolerance(t); self }
@@ -344,11 +392,21 @@ impl<T: SapcaFloat> MaskedSparsePCABuilder<T> {
     pub fn svd_method(mut self, m: SVDMethod) -> Self { self.base = self.base.svd_method(m); self }
     pub fn mask(mut self, mask: Vec<bool>) -> Self { self.mask = mask; self }
     pub fn devices(mut self, d: Vec<i32>) -> Self { self.base = self.base.devices(d); self }
-    pub fn build(self) -> Result<MaskedSparsePCA<T>> {
-        let b = self.base;
-        let h = create(b.n_components, b.alpha, b.tolerance, b.random_seed.unwrap_or(42), b.center,
-                       b.verbose, b.svdmethod, Some(&self.mask), &b.devices)?;
-        Ok(MaskedSparsePCA { inner: SparsePCA { h, n_components: b.n_components, _t: PhantomData }, mask_len: self.mask.len() })
+    /// sparse_masked/mod.rs:146-160: infallible
+    pub fn build(self) -> MaskedSparsePCA<T> {
+        let mask_len = self.mask.len();
+        let cfg = self.base.config(Some(self.mask));
+        MaskedSparsePCA { inner: SparsePCA::from_config(cfg), mask_len }
+    }
+}
+
+/// The reference's module tree (src/dimred/pca/mod.rs:36-42; README.md:51-53 imports
+/// `dimred::pca::{SparsePCABuilder, SVDMethod}` and `dimred::pca::sparse::PowerIterationNormalizer`).
+pub mod dimred {
+    pub mod pca {
+        pub use crate::{MaskedSparsePCA, MaskedSparsePCABuilder, PowerIterationNormalizer, SVDMethod, SparsePCA, SparsePCABuilder};
+        pub mod sparse { pub use crate::{PowerIterationNormalizer, SparsePCA, SparsePCABuilder}; }
+        pub mod sparse_masked { pub use crate::{MaskedSparsePCA, MaskedSparsePCABuilder}; }
     }
 }
 

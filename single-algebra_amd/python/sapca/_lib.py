@@ -45,18 +45,21 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int3
 _TYPED = [
     "sapca_set_omega", "sapca_fit_csr", "sapca_transform_csr", "sapca_fit_transform_csr",
     "sapca_fit_csr_device", "sapca_transform_csr_device", "sapca_fit_transform_csr_device",
+    "sapca_transform_csr_device_to_host", "sapca_fit_transform_csr_device_to_host",
     "sapca_get_components", "sapca_get_singular_values", "sapca_get_explained_variance", "sapca_get_mean",
     "sapca_get_explained_variance_ratio", "sapca_get_cumulative_explained_variance_ratio",
     "sapca_get_feature_importances", "sapca_colstats_csr", "sapca_spmm_csr", "sapca_spmmt_csr",
     "sapca_normalize_panel", "sapca_generate_omega",
     "sapca_upload_csr", "sapca_normalize_csr_device", "sapca_log1p_csr_device", "sapca_stats_csr_device",
     "sapca_multi_fit_csr", "sapca_multi_transform_csr", "sapca_multi_fit_transform_csr",
+    "sapca_multi_upload_csr", "sapca_multi_transform_resident", "sapca_multi_fit_transform_resident",
 ]
 _PLAIN = [
     "sapca_options_default", "sapca_abi_version", "sapca_create", "sapca_destroy", "sapca_last_error",
     "sapca_set_mask", "sapca_get_dims", "sapca_get_total_variance", "sapca_get_mask_index_maps",
     "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_rccl_available", "sapca_comm_init_rank",
-    "sapca_comm_set_callback", "sapca_comm_allreduce", "sapca_upload_values_changed",
+    "sapca_comm_set_callback", "sapca_comm_allreduce", "sapca_comm_abort", "sapca_comm_async_error", "sapca_comm_has_side_lane",
+    "sapca_upload_values_changed", "sapca_multi_fit_resident", "sapca_multi_resident_shard",
     "sapca_multi_create", "sapca_multi_destroy", "sapca_multi_last_error", "sapca_multi_n_devices", "sapca_multi_member",
     "sapca_multi_uses_rccl", "sapca_multi_set_mask",
 ]
@@ -105,6 +108,10 @@ def load():
     lib.sapca_multi_n_devices.argtypes = [C.c_void_p]
     lib.sapca_multi_n_devices.restype = C.c_uint32
     lib.sapca_multi_uses_rccl.argtypes = [C.c_void_p]
+    lib.sapca_multi_fit_resident.argtypes = [C.c_void_p]
+    lib.sapca_comm_abort.argtypes = [C.c_void_p]
+    lib.sapca_comm_async_error.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.sapca_comm_has_side_lane.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 

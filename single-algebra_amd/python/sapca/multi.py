@@ -91,14 +91,67 @@ class MultiDevice:
             mem._dtype64 = dt == np.float64
         return out
 
+    # ---- resident shards: upload once, fit / project repeatedly without PCIe (sapca_multi_upload_csr_*) ----
+    def upload(self, x):
+        import scipy.sparse as sp
+        if not sp.isspmatrix_csr(x):
+            raise TypeError("expected a scipy.sparse.csr_matrix")
+        if not x.has_sorted_indices:
+            x = x.sorted_indices()
+        dt = np.dtype(x.dtype)
+        suf, ct = _SUF[dt]
+        m, n = x.shape
+        if self._mask is not None and self._mask.size != n:
+            raise L.SapcaError(L.ERR_MASK_LEN, "The mask vector length and the number of features (columns) have to be the same!")
+        ro, ci, va = as_u64(x.indptr), as_u64(x.indices), np.ascontiguousarray(x.data)
+        self._check(getattr(L.load(), f"sapca_multi_upload_csr_{suf}")(
+            self._mh, C.c_uint64(m), C.c_uint64(n), C.c_uint64(va.size), _np_ptr(ro, C.c_uint64), _np_ptr(ci, C.c_uint64), _np_ptr(va, ct)))
+        self._resident = (m, dt)
+        return self
+
+    def _resident_call(self, op):
+        if getattr(self, "_resident", None) is None:
+            raise L.SapcaError(L.ERR_ARG, "no resident matrix: call upload() first")
+        m, dt = self._resident
+        suf, ct = _SUF[dt]
+        lib = L.load()
+        out = None
+        if op == "fit":
+            self._check(lib.sapca_multi_fit_resident(self._mh))
+        else:
+            out = np.empty((m, self.n_components), dtype=dt)
+            self._check(getattr(lib, f"sapca_multi_{op}_resident_{suf}")(self._mh, _np_ptr(out, ct)))
+        for mem in self._members:
+            mem._dtype64 = dt == np.float64
+        return out
+
+    def fit_resident(self):
+        self._resident_call("fit")
+        return self
+
+    def transform_resident(self):
+        return self._resident_call("transform")
+
+    def fit_transform_resident(self):
+        return self._resident_call("fit_transform")
+
+    def resident_shard(self, i):
+        """(first_row, rows, nnz) of member i's resident shard"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(L.load().sapca_multi_resident_shard(self._mh, C.c_uint32(i), C.byref(a), C.byref(b), C.byref(c), None, None, None))
+        return a.value, b.value, c.value
+
     def fit(self, x):
+        self._resident = None
         self._call("fit", x, False)
         return self
 
     def transform(self, x):
+        self._resident = None
         return self._call("transform", x, True)
 
     def fit_transform(self, x):
+        self._resident = None
         return self._call("fit_transform", x, True)
 
     def __getattr__(self, name):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/sapca.h but not exported"
     assert declared == set(L.EXPORTED_SYMBOLS)
-    assert lib.sapca_abi_version() == 3
+    assert lib.sapca_abi_version() == 4
 
 
 def test_options_struct_layout_matches_header():
@@ -82,3 +82,74 @@ def test_cpp_mirror_compiles(tmp_path):
                    % os.path.join(root, "single-algebra_amd", "host", "cpp", "sapca.hpp"))
     r = subprocess.run([cxx, "-std=c++17", "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def _header_functions():
+    """(name -> argument count) of every function include/sapca.h declares: an independent, cruder parse than the
+    generator's (comments stripped, `name(args);` with the commas counted)."""
+    text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "sapca.h")).read(), flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(sapca_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        if name == "sapca_allreduce_fn":
+            continue
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_sys_crate_declares_the_whole_header():
+    """host/rust/sapca-sys/src/lib.rs is generated from the header (tools/gen_sapca_sys.py): every function, the same
+    argument count, and the committed file is what the generator writes today."""
+    import subprocess
+    import sys
+    rs = open(os.path.join(ROOT, "single-algebra_amd", "host", "rust", "sapca-sys", "src", "lib.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    have = {}
+    for name, args in re.findall(r"pub fn (sapca_\w+)\(([^()]*)\)", block):
+        args = args.strip()
+        have[name] = 0 if not args else args.count(":")
+    want = _header_functions()
+    assert set(have) == set(want), (sorted(set(want) - set(have)), sorted(set(have) - set(want)))
+    for name, n in want.items():
+        assert have[name] == n, f"{name}: header has {n} arguments, sapca-sys {have[name]}"
+    assert len(want) >= 91
+    # struct layouts: field counts and order of the two POD structs
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "sapca.h")).read(), flags=re.S)
+    for struct, cls in (("sapca_options", L.Options), ("sapca_timings", L.Timings)):
+        body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}" % struct, hdr, flags=re.S).group(1)
+        c_fields = [re.match(r".*?(\w+)\s*(?:\[\d+\])?$", " ".join(d.split())).group(1) for d in body.split(";") if d.strip()]
+        r_body = re.search(r"pub struct %s \{(.*?)\}" % struct, rs, flags=re.S).group(1)
+        r_fields = re.findall(r"pub (\w+):", r_body)
+        assert c_fields == r_fields == [f[0] for f in cls._fields_], struct
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_sapca_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the safe wrapper only calls functions the sys crate declares
+    wrapper = open(os.path.join(ROOT, "single-algebra_amd", "host", "rust", "sapca", "src", "lib.rs")).read()
+    for name in set(re.findall(r"ffi::\$?(sapca_[a-z0-9_]+)\b", wrapper) + re.findall(r"\b(sapca_[a-z0-9_]+_f(?:32|64))\b", wrapper)) - \
+            {"sapca_handle", "sapca_multi", "sapca_options"}:
+        assert name in have, f"host/rust/sapca uses {name}, which include/sapca.h does not declare"
+
+
+def test_rust_builders_are_infallible_like_the_reference():
+    """`SparsePCABuilder::build()` / `MaskedSparsePCABuilder::build()` return the estimator itself
+    (/root/reference/src/dimred/pca/sparse/mod.rs:470-483, sparse_masked/mod.rs:146-160; README.md:56-66 writes
+    `.build();` and then `pca.fit_transform(..)`): the wrapper must not hand back a Result there."""
+    wrapper = open(os.path.join(ROOT, "single-algebra_amd", "host", "rust", "sapca", "src", "lib.rs")).read()
+    assert re.search(r"pub fn build\(self\) -> SparsePCA<T>\s*\{", wrapper)
+    assert re.search(r"pub fn build\(self\) -> MaskedSparsePCA<T>\s*\{", wrapper)
+    assert "pub fn build(self) -> Result" not in wrapper
+    # the reference's constructors, same arity (sparse/mod.rs:63-71, sparse_masked/mod.rs:214-223)
+    assert re.search(r"pub fn new\(n_components: usize, alpha: T, tollerance: Option<T>, random_seed: Option<u32>, center: bool, verbose: bool,\s*svdmethod: SVDMethod\) -> Self", wrapper)
+    assert re.search(r"pub fn new\(n_components: usize, alpha: T, tollerance: Option<T>, random_seed: Option<u32>, mask: Vec<bool>, center: bool,\s*verbose: bool, svd_method: SVDMethod\) -> Self", wrapper)
+
+
+def test_generated_sweep_loop_is_what_its_generator_writes(tmp_path):
+    """csrc/spmm_dq2_gen.h (10.7 k lines of inline asm) is committed generator output: regenerate and compare."""
+    import subprocess
+    import sys
+    out = tmp_path / "gen.h"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DQ2_")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_spmm_dq2.py"), str(out)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    committed = open(os.path.join(ROOT, "single-algebra_amd", "csrc", "spmm_dq2_gen.h")).read()
+    assert out.read_text() == committed, "spmm_dq2_gen.h is stale: run python tools/gen_spmm_dq2.py"

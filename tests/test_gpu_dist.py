@@ -155,3 +155,39 @@ def test_rccl_binding_with_a_one_rank_communicator(monkeypatch):
     monkeypatch.delenv("SAPCA_COMM_FORCE_RCCL")
     lz_ref.fit(x)
     np.testing.assert_allclose(lz.singular_values_(np.float64), lz_ref.singular_values_(np.float64), rtol=1e-12)
+
+
+def test_rccl_communicator_can_be_aborted_and_rebuilt(monkeypatch):
+    """The built-in RCCL binding on a one-rank communicator (SAPCA_COMM_FORCE_RCCL=1 routes every all-reduce site through
+    ncclAllReduce): the side stream gets its own communicator (ncclCommSplit), sapca_comm_abort ends the communicators --
+    the next fit fails at once with SAPCA_ERR_COMM instead of entering a collective -- and a new sapca_comm_init_rank
+    brings the handle back.  What a host program (or sapca_multi) does when a peer rank has failed."""
+    import ctypes as C
+    import sapca
+    from sapca import _lib as L
+    from sapca import synth
+    lib = L.load()
+    if not lib.sapca_comm_rccl_available():
+        pytest.skip("librccl does not resolve")
+    monkeypatch.setenv("SAPCA_COMM_FORCE_RCCL", "1")
+    m, n, k = 3000, 500, 5
+    dev = synth.gapped_csr(m, n, 0.06, k, seed=4, dtype=torch.float32, device="cuda")
+    x = sapca.DeviceCsr(*dev, (m, n))
+    est = sapca.SparsePCABuilder.new().n_components(k).svd_method(sapca.SVDMethod.Random(5, 2)).build()
+    ident = (C.c_uint8 * 128)()
+    assert lib.sapca_comm_unique_id(ident) == L.OK
+    L.check(est._h, lib.sapca_comm_init_rank(est._h, C.c_uint32(1), C.c_uint32(0), ident))
+    state = C.c_int32(7)
+    assert lib.sapca_comm_async_error(est._h, C.byref(state)) == L.OK and state.value == 0
+    lane = lib.sapca_comm_has_side_lane(est._h)
+    assert lane in (0, 1)
+    t0 = est.fit_transform(x).cpu().numpy()
+    assert lib.sapca_comm_abort(est._h) == L.OK
+    assert lib.sapca_comm_async_error(est._h, C.byref(state)) == L.OK and state.value == -1
+    with pytest.raises(L.SapcaError, match="communicator aborted") as e:
+        est.fit_transform(x)
+    assert e.value.status == L.ERR_COMM
+    assert lib.sapca_comm_unique_id(ident) == L.OK
+    L.check(est._h, lib.sapca_comm_init_rank(est._h, C.c_uint32(1), C.c_uint32(0), ident))
+    t1 = est.fit_transform(x).cpu().numpy()
+    np.testing.assert_allclose(t1, t0, atol=1e-5 * np.abs(t0).max())

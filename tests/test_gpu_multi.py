@@ -111,3 +111,60 @@ def test_transposed_sweep_in_two_pieces_with_the_first_all_reduce_behind_the_sec
     one = make().set_omega(om)
     one.fit(A)
     assert O.subspace_angle(res["1"][1], one.components_(np.float64)) < 2e-5
+
+
+def test_resident_shards_are_uploaded_once_and_fitted_repeatedly():
+    """sapca_multi_upload_csr_* + the *_resident calls (SURVEY.md 8f-1 for several devices): the shards cross PCIe once; fits
+    with another k / seed and the projection reuse them.  Same numbers as the host-matrix calls of the same sapca_multi."""
+    m, n, k, p, q = 8000, 1100, 8, 6, 2
+    A = _host(m, n, 0.05, k, 17, torch.float32)
+    om = synth.gaussian_panel(n, k + p, 5).numpy()
+    make = lambda: sapca.SparsePCABuilder.new().n_components(k).svd_method(SVDMethod.Random(p, q, PIN.QR)).build()
+    md = sapca.MultiDevice(make(), [0, 0, 0]).set_omega(om)
+    t_host = md.fit_transform(A)
+    comps_host = md.components_(np.float64).copy()
+    md.upload(A)
+    rows = [md.resident_shard(i) for i in range(3)]
+    assert rows[0][0] == 0 and sum(r[1] for r in rows) == m and sum(r[2] for r in rows) == A.nnz
+    assert all(rows[i][0] + rows[i][1] == rows[i + 1][0] for i in range(2))
+    for _ in range(2):   # repeated fits of the resident shards
+        t = md.fit_transform_resident()
+        np.testing.assert_allclose(t, t_host, atol=1e-5 * np.abs(t_host).max())
+        assert O.subspace_angle(md.components_(np.float64), comps_host) < 1e-6
+    md.fit_resident()
+    t2 = md.transform_resident()
+    np.testing.assert_allclose(t2, t_host, atol=2e-4 * np.abs(t_host).max())
+    # a host-matrix call drops the resident shards (the members' upload buffers were reused)
+    md.fit(A)
+    with pytest.raises(L.SapcaError, match="no resident matrix"):
+        md.fit_transform_resident()
+    # f64 shards on the same sapca_multi; the f32 call on them is refused
+    A64 = A.astype(np.float64)
+    md64 = sapca.MultiDevice(sapca.SparsePCABuilder.new().n_components(k).svd_method(SVDMethod.Lanczos()).build(), [0, 0])
+    md64.upload(A64)
+    t64 = md64.fit_transform_resident()
+    one = sapca.SparsePCABuilder.new().n_components(k).svd_method(SVDMethod.Lanczos()).build()
+    t1 = one.fit_transform(A64)
+    np.testing.assert_allclose(md64.singular_values_(np.float64), one.singular_values_(np.float64), rtol=1e-8)
+    np.testing.assert_allclose(t64, t1, atol=1e-6 * np.abs(t1).max())
+
+
+def test_a_failing_resident_shard_releases_its_peers():
+    """a member that fails inside a resident fit (here: n_components above its shard's... the mask of another width) ends the
+    call for all members without a hang, and the sapca_multi stays usable"""
+    m, n, k = 5000, 600, 5
+    A = _host(m, n, 0.05, k, 2, torch.float32)
+    md = sapca.MultiDevice(sapca.MaskedSparsePCABuilder.new().n_components(k).mask(np.ones(n, bool))
+                           .svd_method(SVDMethod.Random(4, 1, PIN.QR)).build(), [0, 0])
+    md.upload(A)
+    assert md.fit_transform_resident().shape == (m, k)
+    # break ONE member only: its mask no longer fits, it fails before its first collective while member 0 enters it
+    lib = L.load()
+    bad = np.ones(n + 1, np.uint8)
+    import ctypes as C
+    lib.sapca_set_mask(md.member(1)._h, bad.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(bad.size))
+    with pytest.raises(L.SapcaError, match="shard 1.*mask vector length"):
+        md.fit_transform_resident()
+    good = np.ones(n, np.uint8)
+    lib.sapca_set_mask(md.member(1)._h, good.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(good.size))
+    assert md.fit_transform_resident().shape == (m, k)

@@ -602,6 +602,34 @@ def test_malformed_host_csr_is_refused(session):
         session.spmm(np.array([0, 2, 3, 5], dtype=np.int64), np.array([0, 1, 2, 3, 4], dtype=np.int64), val, 3, 4, X)
 
 
+def test_rows_whose_columns_do_not_ascend_give_numbers_not_stray_accesses():
+    """include/sapca.h: a device CSR with unsorted rows gives wrong numbers, not stray accesses.  The gather fill of A^T's
+    format reads runs of A's rows whose ends the histogram pass found assuming ascending columns: that pass now notices a
+    row whose columns go back to an earlier block, and the builder takes the bucket route (every column through a table)
+    instead.  The handle then fits a sane matrix as if nothing had happened."""
+    m, n, k = 40_000, 2600, 6
+    dev = synth.gapped_csr(m, n, 0.03, k, seed=11, dtype=torch.float32, device="cuda")
+    ptr, idx, val = dev
+    bad_idx, bad_val = idx.clone(), val.clone()
+    p = ptr.cpu().numpy()
+    for r in (17, 4242, m - 1):   # rows reversed end to end: their columns descend through every block
+        lo, hi = int(p[r]), int(p[r + 1])
+        assert hi - lo > 8
+        bad_idx[lo:hi] = torch.flip(idx[lo:hi], dims=[0])
+        bad_val[lo:hi] = torch.flip(val[lo:hi], dims=[0])
+    pca = _builder(k, 6, 2).spmm_variant(2).build()
+    try:
+        t_bad = pca.fit_transform(sapca.DeviceCsr(ptr, bad_idx, bad_val, (m, n)))
+        assert t_bad.shape == (m, k)
+        torch.cuda.synchronize()
+    except L.SapcaError as e:   # (a refusal would be fine too; a fault is not)
+        assert e.status in (L.ERR_ARG, L.ERR_SVD)
+    good = _builder(k, 6, 2).spmm_variant(2).build()
+    t_ref = good.fit_transform(sapca.DeviceCsr(ptr, idx, val, (m, n)))
+    t_again = pca.fit_transform(sapca.DeviceCsr(ptr, idx, val, (m, n)))
+    assert torch.equal(t_again, t_ref)
+
+
 def test_explained_variance_ratio_sums_to_one_q4():
     ptr, idx, val = csr_np(synth.gapped_csr(2000, 500, 0.08, 6, seed=3, dtype=torch.float32))
     pca = _builder(6, 6, 2).build()
