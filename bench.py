@@ -151,20 +151,12 @@ def self_launch(args):
     raise SystemExit(proc.returncode)
 
 
-def measured_copy_gbs(dev, nbytes=1 << 30, reps=5):
-    """Attainable HBM rate of this device: a device-to-device copy of `nbytes` (read + write counted), best of `reps`."""
-    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
-    dst = torch.empty_like(src)
-    best = float("inf")
-    for _ in range(reps + 1):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        dst.copy_(src)
-        b.record()
-        b.synchronize()
-        best = min(best, a.elapsed_time(b))
-    del src, dst
-    return 2.0 * nbytes / (best * 1e-3) / 1e9
+def measured_copy_gbs(local_rank, nbytes=1 << 30, reps=5):
+    """Attainable HBM rate of this device: the library's own 16-byte-per-lane streaming copy of `nbytes` (read + write
+    counted, best of `reps`; sapca_measure_copy_gbs) -- not a framework memcpy."""
+    import sapca
+    est = sapca.SparsePCABuilder.new().device(local_rank).build()
+    return est.measure_copy_gbs(nbytes, reps)
 
 
 def c1_comparison(dev, local_rank):
@@ -278,7 +270,19 @@ def run_randomized(workload, scaling, steps, warmup, rank, world, local_rank, de
     dt = time.perf_counter() - t0
     avg_sweep_ms = float(np.mean(sweep_ms)) if sweep_ms else float("nan")
     per_rank_sweep = [avg_sweep_ms]
+    t_last = pca.timings()
+    per_rank_comm = [{"rank": rank, "transport": transport, "comm_ms": stage.get("comm_ms", 0.0),
+                      "at_sweep_pieces": int(t_last.at_sweep_pieces), "side_lane": bool(pca.comm_has_side_lane()) if world > 1 else False}]
     if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank_comm[0])
+        per_rank_comm = gathered
+        if len({g["transport"] for g in gathered}) != 1 or len({g["at_sweep_pieces"] for g in gathered}) != 1:
+            # (ranks that disagree on the transport or on the piece count would have mismatched collectives: say so and leave,
+            #  on every rank, instead of reporting a number from a run that only happened not to hang)
+            if rank == 0:
+                print(f"bench.py: ranks disagree on the collective transport / sweep pieces: {gathered}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
         tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -299,7 +303,7 @@ def run_randomized(workload, scaling, steps, warmup, rank, world, local_rank, de
     res = {"workload": workload, "scaling": scaling, "m_total": m_total, "m": m, "n": n, "density": density, "k": k, "p": p, "q": q,
            "seed": seed, "nnz": nnz, "nnz_total": nnz_total, "dt": dt, "steps": steps, "ms_per_step": dt / steps * 1e3,
            "value": total_bytes / (dt / steps) / 1e9, "stage": stage, "transport": transport, "sweep_ms": sweep_ms,
-           "avg_sweep_ms": avg_sweep_ms, "per_rank_sweep": per_rank_sweep, "sweep_bytes": sweep_bytes,
+           "avg_sweep_ms": avg_sweep_ms, "per_rank_sweep": per_rank_sweep, "per_rank_comm": per_rank_comm, "sweep_bytes": sweep_bytes,
            "achieved": sweep_bytes / (avg_sweep_ms * 1e-3) / 1e9, "sweep_kernel": int(t.sweep_kernel),
            "slots": 0.5 * (t.sweep_slots_a + t.sweep_slots_at)}
     del out, x, ptr, idx, val, pca
@@ -411,7 +415,8 @@ def main():
                                    f"SparsePCA fit_transform, SVDMethod::Random k={k} p={p} q={q} QR, rows range-partitioned "
                                    f"over {world} GPU(s) ({args.scaling} scaling), inputs resident in HBM, collectives: {r['transport']}",
                        "nnz": int(r["nnz_total"]), "rows_per_gpu": r["m"], "sweeps_per_fit": 2 * q + 2, "stage_ms": r["stage"],
-                       "collectives": r["transport"], "comm_ms": r["stage"].get("comm_ms", 0.0), "sweep_ms_per_rank": r["per_rank_sweep"]},
+                       "collectives": r["transport"], "comm_ms": r["stage"].get("comm_ms", 0.0), "sweep_ms_per_rank": r["per_rank_sweep"],
+                       "comm_per_rank": r["per_rank_comm"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": f"{kernel_names.get(r['sweep_kernel'], '?')}: spmm sweep (A*X and A^T*Y launches, HIP events on the library stream)",
@@ -424,10 +429,13 @@ def main():
             line["roofline"]["secondary"] = {"bound": "lds", "achieved": lds_bytes / (avg_sweep_ms * 1e-3) / 1e9, "peak": 150000.0,
                                              "unit": "GB/s", "frac": lds_bytes / (avg_sweep_ms * 1e-3) / 1e9 / 150000.0,
                                              "lds_gather_bytes_per_launch": lds_bytes, "entry_slots_per_launch": slots,
-                                             "stored_entries_per_launch": int(r["nnz"])}
+                                             "stored_entries_per_launch": int(r["nnz"]),
+                                             # the same on STORED entries only (padding slots are not work): the honest figure
+                                             "frac_stored": int(r["nnz"]) * 256.0 / (avg_sweep_ms * 1e-3) / 1e9 / 150000.0}
         line.update(extra)
         if not args.no_extras:
-            peak_meas = measured_copy_gbs(dev)
+            peak_meas = measured_copy_gbs(local_rank)
+            line["roofline"]["peak_measured_by"] = "sapca_measure_copy_gbs: 1 GiB, 16 B per lane, read + write"
             line["roofline"]["peak_measured"] = peak_meas
             line["roofline"]["frac_of_measured"] = achieved / peak_meas
         if isinstance(e2e, tuple):

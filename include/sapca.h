@@ -304,6 +304,11 @@ sapca_status sapca_stats_csr_device_f64(sapca_handle h, uint64_t m, uint64_t n, 
                                         int32_t direction, double* sum, double* sum_squared, uint64_t* nonzero,
                                         double* min_out, double* max_out);
 
+/* Measurement support: the rate (GB/s, read + write counted) of a 16-byte-per-lane streaming copy of `bytes`
+ * bytes on the handle's device, best of `reps` -- the HBM rate a kernel of this library can attain, reported by
+ * bench.py beside the data-sheet peak.  Allocates and frees its two buffers.                       */
+sapca_status sapca_measure_copy_gbs(sapca_handle h, uint64_t bytes, uint32_t reps, double* gbs);
+
 /* ---- multi-GPU: one process per GPU, rows range-partitioned ---------------- */
 /* nnz-balanced contiguous row ranges: bounds[0]=0 <= ... <= bounds[nparts]=m.  Pure host code. */
 sapca_status sapca_partition_rows(uint64_t m, const uint64_t* row_offsets, uint32_t nparts, uint64_t* bounds);

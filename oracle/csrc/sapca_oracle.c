@@ -210,15 +210,24 @@ int orc_num_threads(void) {
   /* R11: SVD of B^T (n x l, row-major in Z) by one-sided Jacobi (Hestenes): on exit the */       \
   /* columns of Z are sigma_j * (right-vectors-of-B)_j; returns sigma sorted descending   */      \
   /* with order[] giving the column permutation.                                          */      \
-  static void jacobi_cols_##SUF(T* Z, uint64_t n, uint64_t l, double* sig, uint64_t* order) {     \
+  static void jacobi_cols_##SUF(T* Zrm, uint64_t n, uint64_t l, double* sig, uint64_t* order) {   \
+    /* the rotations work on a column-major copy: a column is one contiguous run of n values   */   \
+    /* (row-major, every pass over a column pair touched n cache lines per column: minutes at  */   \
+    /* l = 110).  Same rotations, same summation order along a column.                          */  \
+    T* Z = (T*)malloc(n * l * sizeof(T));                                                         \
+    _Pragma("omp parallel for schedule(static)")                                                  \
+    for (uint64_t j = 0; j < l; ++j)                                                              \
+      for (uint64_t i = 0; i < n; ++i) Z[j * n + i] = Zrm[i * l + j];                             \
     for (int sweep = 0; sweep < 60; ++sweep) {                                                    \
       double off = 0;                                                                             \
       for (uint64_t p = 0; p + 1 < l; ++p)                                                        \
         for (uint64_t q = p + 1; q < l; ++q) {                                                    \
+          T* zp_ = Z + p * n;                                                                     \
+          T* zq_ = Z + q * n;                                                                     \
           double a = 0, b = 0, g = 0;                                                             \
           _Pragma("omp parallel for reduction(+ : a, b, g) schedule(static)")                     \
           for (uint64_t i = 0; i < n; ++i) {                                                      \
-            double zp = Z[i * l + p], zq = Z[i * l + q];                                          \
+            double zp = zp_[i], zq = zq_[i];                                                      \
             a += zp * zp; b += zq * zq; g += zp * zq;                                             \
           }                                                                                       \
           if (a == 0 || b == 0) continue;                                                         \
@@ -230,19 +239,23 @@ int orc_num_threads(void) {
           double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                       \
           _Pragma("omp parallel for schedule(static)")                                            \
           for (uint64_t i = 0; i < n; ++i) {                                                      \
-            double zp = Z[i * l + p], zq = Z[i * l + q];                                          \
-            Z[i * l + p] = (T)(cs * zp - sn * zq);                                                \
-            Z[i * l + q] = (T)(sn * zp + cs * zq);                                                \
+            double zp = zp_[i], zq = zq_[i];                                                      \
+            zp_[i] = (T)(cs * zp - sn * zq);                                                      \
+            zq_[i] = (T)(sn * zp + cs * zq);                                                      \
           }                                                                                       \
         }                                                                                         \
       if (off < (sizeof(T) == 4 ? 5e-7 : 1e-14)) break;                                           \
     }                                                                                             \
     for (uint64_t j = 0; j < l; ++j) {                                                            \
       double a = 0;                                                                               \
-      for (uint64_t i = 0; i < n; ++i) a += (double)Z[i * l + j] * Z[i * l + j];                  \
+      for (uint64_t i = 0; i < n; ++i) a += (double)Z[j * n + i] * Z[j * n + i];                  \
       sig[j] = sqrt(a);                                                                           \
       order[j] = j;                                                                               \
     }                                                                                             \
+    _Pragma("omp parallel for schedule(static)")                                                  \
+    for (uint64_t i = 0; i < n; ++i)                                                              \
+      for (uint64_t j = 0; j < l; ++j) Zrm[i * l + j] = Z[j * n + i];                             \
+    free(Z);                                                                                      \
     for (uint64_t i = 0; i < l; ++i)                                                              \
       for (uint64_t j = i + 1; j < l; ++j)                                                        \
         if (sig[order[j]] > sig[order[i]]) { uint64_t t = order[i]; order[i] = order[j]; order[j] = t; } \

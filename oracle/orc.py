@@ -28,6 +28,14 @@ def lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
+        # OpenMP's default is every CPU the machine shows; a GPU box hands a job a share of them (16 per GPU).  Hundreds of
+        # threads on 16 cores turn the restatement's many short parallel regions (the Jacobi rotations, the Householder
+        # columns) into minutes of barrier waits: the default here is the share this process may actually run on.
+        try:
+            share = len(os.sched_getaffinity(0))
+        except AttributeError:
+            share = os.cpu_count() or 1
+        _lib.orc_set_num_threads(C.c_int(max(1, min(share, int(os.environ.get("ORC_MAX_THREADS", "16"))))))
     return _lib
 
 

@@ -106,7 +106,7 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
   int* flag = reinterpret_cast<int*>(d64 + m + 1);
   SAPCA_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
   SAPCA_HIP(hipMemcpyAsync(d64, row_offsets, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-  static const bool on_device = getenv("SAPCA_UPLOAD_NARROW_ON_DEVICE") != nullptr;   // the first version: ship u64, narrow on the GPU
+  static const bool on_device = sapca::dbg_env("SAPCA_UPLOAD_NARROW_ON_DEVICE") != nullptr;   // the first version: ship u64, narrow on the GPU
   bool bad_host = false, stats_here = false;
   void* stats_work = nullptr;
   if (nnz == 0 || !on_device) sapca::k::narrow_indices(d64, d64, (int64_t)m, 0, (int64_t)n, d_ptr, d_idx, flag, s);   // row offsets only
@@ -123,7 +123,7 @@ CsrView<T> upload(sapca_handle h, uint64_t m, uint64_t n, uint64_t nnz, const ui
         h->up_stage[b].ensure(chunk * sizeof(int32_t));
         if (!h->up_done[b]) SAPCA_HIP(hipEventCreateWithFlags(&h->up_done[b], hipEventDisableTiming));
       }
-      static const bool stats_off = getenv("SAPCA_UPLOAD_STATS_OFF") != nullptr;
+      static const bool stats_off = sapca::dbg_env("SAPCA_UPLOAD_STATS_OFF") != nullptr;
       stats_here = with_stats && !stats_off && n > 0 && sapca::k::exact_colstats_bytes<T>((int64_t)n) <= ((size_t)1 << 30);
       if (stats_here) {
         ensure_side_stream(h);
@@ -841,6 +841,43 @@ sapca_status sapca_upload_values_changed(sapca_handle h) {
   return guarded(h, [&] {
     h->prep_key.valid = false;
     h->up_stats.valid = false;
+  });
+}
+
+sapca_status sapca_measure_copy_gbs(sapca_handle h, uint64_t bytes, uint32_t reps, double* gbs) {
+  return guarded(h, [&] {
+    SAPCA_CHECK(gbs != nullptr && bytes >= 4096 && reps >= 1, SAPCA_ERR_ARG, "measure_copy_gbs: bytes >= 4096, reps >= 1");
+    bytes &= ~(uint64_t)15;
+    void *src = nullptr, *dst = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    auto cleanup = [&] {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      if (src) (void)hipFree(src);
+      if (dst) (void)hipFree(dst);
+    };
+    try {
+      SAPCA_HIP(hipMalloc(&src, bytes));
+      SAPCA_HIP(hipMalloc(&dst, bytes));
+      SAPCA_HIP(hipMemsetAsync(src, 1, bytes, h->stream));
+      SAPCA_HIP(hipEventCreate(&a));
+      SAPCA_HIP(hipEventCreate(&b));
+      float best = 0;
+      for (uint32_t r = 0; r <= reps; ++r) {   // (the first pass also faults the pages in)
+        SAPCA_HIP(hipEventRecord(a, h->stream));
+        sapca::k::stream_copy16(src, dst, (int64_t)bytes, h->stream);
+        SAPCA_HIP(hipEventRecord(b, h->stream));
+        SAPCA_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        SAPCA_HIP(hipEventElapsedTime(&ms, a, b));
+        if (r > 0 && (best == 0 || ms < best)) best = ms;
+      }
+      *gbs = 2.0 * (double)bytes / ((double)best * 1e-3) / 1e9;
+    } catch (...) {
+      cleanup();
+      throw;
+    }
+    cleanup();
   });
 }
 

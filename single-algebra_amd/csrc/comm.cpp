@@ -82,7 +82,7 @@ void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
   rank = rank_;
   // a one-rank job needs no collective; SAPCA_COMM_FORCE_RCCL=1 still builds the communicator and
   // routes every all-reduce site through RCCL (a copy), which is how a one-GPU box tests the binding
-  if (nranks == 1 && !getenv("SAPCA_COMM_FORCE_RCCL")) { mode = NONE; return; }
+  if (nranks == 1 && !dbg_env("SAPCA_COMM_FORCE_RCCL")) { mode = NONE; return; }
   RcclId u;
   std::memcpy(u.internal, id, 128);
   ncclComm_t c = nullptr;
@@ -92,7 +92,7 @@ void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
   aborted.store(false);
   // the side stream's communicator: a collective split with one colour (every rank enters it right behind the init)
   rccl_comm2 = nullptr;
-  if (api().CommSplit && getenv("SAPCA_COMM_NO_SPLIT") == nullptr) {
+  if (api().CommSplit && dbg_env("SAPCA_COMM_NO_SPLIT") == nullptr) {
     ncclComm_t c2 = nullptr;
     if (api().CommSplit(c, 0, (int)rank, &c2, nullptr) == 0) rccl_comm2 = c2;
   }

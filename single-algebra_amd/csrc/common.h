@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/sapca.h"
+#include "switches.h"
 
 namespace sapca {
 

@@ -1156,6 +1156,51 @@ flip_sign_kernel(const T* __restrict__ VtT, int64_t n, int ld, double* __restric
   if (threadIdx.x == 0) sign[r] = (n > 0 && (double)VtT[best_i[0] * ld + r] < 0) ? -1.0 : 1.0;
 }
 
+// The same in two coalesced stages for the usual leading dimensions (256 % ld == 0): a block scans a run of rows with a thread
+// per column (the kernel above walks one column per block, 4 bytes out of every row), leaves (|v|, row) of its best per
+// column; the second stage picks the overall best -- larger |v|, the first row on ties -- and reads its sign.
+template <typename T>
+__global__ void __launch_bounds__(256)
+flip_sign_partial_kernel(const T* __restrict__ VtT, int64_t n, int ld, int64_t rows_per_block, double* __restrict__ part_a,
+                         long long* __restrict__ part_i) {
+  __shared__ double best_a[256];
+  __shared__ long long best_i[256];
+  const int c = threadIdx.x % ld, g = threadIdx.x / ld, ng = 256 / ld;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  double ba = -1.0;
+  long long bi = 0x7fffffffffffffffLL;
+  for (int64_t r = r0 + g; r < r1; r += ng) {
+    const double a = fabs((double)VtT[r * ld + c]);
+    if (a > ba) { ba = a; bi = r; }
+  }
+  best_a[threadIdx.x] = ba;
+  best_i[threadIdx.x] = bi;
+  __syncthreads();
+  if (g == 0) {
+    for (int y = 1; y < ng; ++y) {
+      const double oa = best_a[y * ld + c];
+      const long long oi = best_i[y * ld + c];
+      if (oa > ba || (oa == ba && oi < bi)) { ba = oa; bi = oi; }
+    }
+    part_a[(int64_t)blockIdx.x * ld + c] = ba;
+    part_i[(int64_t)blockIdx.x * ld + c] = bi;
+  }
+}
+
+template <typename T>
+__global__ void flip_sign_final_kernel(const T* __restrict__ VtT, int64_t n, int ld, int k, int nblocks, const double* __restrict__ part_a,
+                                       const long long* __restrict__ part_i, double* __restrict__ sign) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double ba = -1.0;
+  long long bi = 0x7fffffffffffffffLL;
+  for (int b = 0; b < nblocks; ++b) {   // (blocks hold ascending row ranges: a strict > keeps the first row on ties)
+    const double oa = part_a[(int64_t)b * ld + c];
+    if (oa > ba) { ba = oa; bi = part_i[(int64_t)b * ld + c]; }
+  }
+  sign[c] = (n > 0 && ba >= 0.0 && (double)VtT[bi * ld + c] < 0) ? -1.0 : 1.0;
+}
+
 template <typename T>
 __global__ void flip_transpose_kernel(const T* __restrict__ VtT, int64_t n, int ld, int k,
                                       const double* __restrict__ sign, T* __restrict__ comps) {
@@ -1443,7 +1488,7 @@ static void chol_inv_host(const double* G, int l, int ld, double* R, double* Rin
 }
 
 void chol_inv(const double* G, int l, int ld, double* R, double* Rinv, int* info, hipStream_t s, const double* wsum, float* vec32, double* vec64) {
-  static const bool general_only = getenv("SAPCA_CHOL_GENERAL") != nullptr;
+  static const bool general_only = dbg_env("SAPCA_CHOL_GENERAL") != nullptr;
   if (!vec32 && !vec64) wsum = nullptr;
   auto tvec = [&] {   // (the variants that do not carry the product in their own epilogue)
     if (!wsum) return;
@@ -1544,7 +1589,7 @@ bool sym_eig_device_ok(int l) {
   // (nine sweeps, 1.9 us per round: two workgroup barriers and a chain of f64 divisions and square roots per round) against
   // 0.27 ms / 1.0 ms for the host's Householder + QL including both crossings -- one workgroup is the wrong machine for
   // this problem, so the host solver stays the default and this kernel documents the attempt.
-  const bool on = getenv("SAPCA_EIG_DEVICE") != nullptr;
+  const bool on = dbg_env("SAPCA_EIG_DEVICE") != nullptr;
   return on && l >= 1 && l <= EIG_MAX_L;
 }
 
@@ -1582,6 +1627,21 @@ void rank1_subtract(T* Z, int64_t rows, int ld, const T* mu, const T* svec, hipS
 
 template <typename T>
 void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBuf& scratch, hipStream_t s, const double** sign_out) {
+  if (ld <= 256 && 256 % ld == 0 && n >= 4096) {
+    int nblocks = (int)std::min<int64_t>(256, (n + 63) / 64);
+    const int64_t rpb = (n + nblocks - 1) / nblocks;
+    nblocks = (int)((n + rpb - 1) / rpb);
+    double* sign = scratch.as<double>((size_t)k + 2 * (size_t)nblocks * ld + 8);
+    double* part_a = sign + ((k + 7) & ~7);
+    long long* part_i = reinterpret_cast<long long*>(part_a + (size_t)nblocks * ld);
+    if (sign_out) *sign_out = sign;
+    hipLaunchKernelGGL((flip_sign_partial_kernel<T>), dim3(nblocks), dim3(256), 0, s, VtT, n, ld, rpb, part_a, part_i);
+    hipLaunchKernelGGL((flip_sign_final_kernel<T>), dim3((k + 63) / 64), dim3(64), 0, s, VtT, n, ld, k, nblocks, part_a, part_i, sign);
+    hipLaunchKernelGGL((flip_transpose_kernel<T>), dim3(grid_for((int64_t)k * n, 256)), dim3(256), 0, s, VtT, n, ld, k,
+                       sign, components);
+    SAPCA_HIP(hipGetLastError());
+    return;
+  }
   double* sign = scratch.as<double>(k);
   if (sign_out) *sign_out = sign;
   hipLaunchKernelGGL((flip_sign_kernel<T>), dim3(k), dim3(256), 0, s, VtT, n, ld, sign);

@@ -131,13 +131,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       // 27 % at 1e7 and loses at 1e6).
       const double entries = (double)nnz * ((double)n_kept / (double)n);
       double floor_entries = sizeof(T) == 4 ? 1e7 : 5e6;
-      if (const char* e = getenv("SAPCA_TILED_MIN_ENTRIES")) floor_entries = atof(e);   // tests: shards either side of the floor
+      if (const char* e = dbg_env("SAPCA_TILED_MIN_ENTRIES")) floor_entries = atof(e);   // tests: shards either side of the floor
       const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes && entries >= floor_entries;
       if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
     }
   }
-  const bool from_at = getenv("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
-  const bool at_tile_major = tiled_ldp != 0 && from_at && getenv("SAPCA_AT_NATURAL") == nullptr;
+  const bool from_at = dbg_env("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
+  const bool at_tile_major = tiled_ldp != 0 && from_at && dbg_env("SAPCA_AT_NATURAL") == nullptr;
   const int tiled_ldp_words = tiled_ldp * (int)sizeof(T) / 4;   // panel row in 4-byte words: what the tile arithmetic counts in
 
   // mask index maps (sparse_masked/mod.rs:264-271 and the HashMap of :462-466)
@@ -189,9 +189,9 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   // come from the same kind of pass over A, on the third stream beside the iterations (a Lanczos fit does not centre:
   // nothing reads them before fit() ends).  What is left of the preparation is the mask compaction.
   // SAPCA_LANCZOS_TRANSPOSE=1 brings the transposed operator (radix sort) back.
-  const bool serial_early = getenv("SAPCA_PREPARE_SERIAL") != nullptr;
+  const bool serial_early = dbg_env("SAPCA_PREPARE_SERIAL") != nullptr;
   bool lz_scatter = h.opt.method == SAPCA_LANCZOS && n_used > 0 && n_used <= m && m >= 4096 && nnz > 0 && k::scatter_fits(n_used) &&
-                    (!masked || !serial_early) && getenv("SAPCA_LANCZOS_TRANSPOSE") == nullptr;
+                    (!masked || !serial_early) && dbg_env("SAPCA_LANCZOS_TRANSPOSE") == nullptr;
   bool lz_side = false;   // its statistics run on the third stream
   if (lz_scatter && !masked) {
     // max |a| for the fixed-point scales (masked fits: the compaction gathers it on its way through the values).  Values that
@@ -213,22 +213,22 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     std::thread& t;
     ~Joiner() { if (t.joinable()) t.join(); }
   } joiner{aside};
-  const bool serial = getenv("SAPCA_PREPARE_SERIAL") != nullptr;
+  const bool serial = dbg_env("SAPCA_PREPARE_SERIAL") != nullptr;
   const bool masked_aside = masked && n_used > 0 && !serial;
   const bool try_direct = sizeof(T) == 4 && at_tile_major && !masked && !serial;   // A^T's format without a transposed CSR
   // Masked fits compact first (MaskedCSRMatrix::new, sparse_masked/mod.rs:313) and transpose only what the mask keeps.  The
   // entries the compaction drops leave as (column, value) pairs: the sums of the masked-out columns (mean_ is full width,
   // sparse_masked/mod.rs:279-286) come from a stable sort of those pairs by column.  On the staged sweep (f32) the
   // compacted matrix then takes the bucket route to A^T's format; otherwise it is transposed into a CSR.
-  const bool try_masked_direct = sizeof(T) == 4 && at_tile_major && masked_aside && n_used <= 65536 && getenv("SAPCA_AT_SORT") == nullptr;
+  const bool try_masked_direct = sizeof(T) == 4 && at_tile_major && masked_aside && n_used <= 65536 && dbg_env("SAPCA_AT_SORT") == nullptr;
   bool compaction_done = false;
   bool side_stats = false;   // the masked-out columns' sums (and the host copy of all statistics) finish on stream3, behind the fit
   // SAPCA_MASK_SUMS_SCATTER=1: single-rank masked fits take those sums straight from A on the third stream (scatter.hip:
   // fixed-point sums in LDS) instead of sorting the (column, value) pairs the compaction writes out for it.  Measured slower
   // on randomized fits (C3's matrix in f32: 14.0 against 12.9 ms): the scatter kernels take a CU's whole LDS, so the sweeps
   // cannot share the chip with them the way they do with the sort's light kernels.  Not the default.
-  const bool scatter_sums = masked && !from_upload && !lz_scatter && !h.comm.active() && getenv("SAPCA_MASK_STATS_INLINE") == nullptr &&
-                            getenv("SAPCA_MASK_SUMS_SCATTER") != nullptr;
+  const bool scatter_sums = masked && !from_upload && !lz_scatter && !h.comm.active() && dbg_env("SAPCA_MASK_STATS_INLINE") == nullptr &&
+                            dbg_env("SAPCA_MASK_SUMS_SCATTER") != nullptr;
   auto scatter_sums_on_stream3 = [&](double* d_drop) {   // sum | sumsq of EVERY column of A (the kept ones are overwritten later)
     unsigned long long* sc = h.lz_scalars.as<unsigned long long>(4);
     k::absmax(A.val, nnz, sc, h.stream3);
@@ -236,7 +236,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   };
   int32_t* drop_col = nullptr;
   T* drop_val = nullptr;
-  if (masked_aside && getenv("SAPCA_MASK_TRANSPOSE_FIRST") == nullptr) {
+  if (masked_aside && dbg_env("SAPCA_MASK_TRANSPOSE_FIRST") == nullptr) {
     Scope sc(h, C_PREPARE);
     int64_t* ca_ptr = h.ca_ptr.as<int64_t>((size_t)m + 1);
     int32_t* ca_idx = h.ca_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
@@ -257,7 +257,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
         SAPCA_HIP(hipEventCreateWithFlags(&h.ev_stats, hipEventDisableTiming));
       }
       if (!h.ev_drop) SAPCA_HIP(hipEventCreateWithFlags(&h.ev_drop, hipEventDisableTiming));
-      side_stats = !h.comm.active() && getenv("SAPCA_MASK_STATS_INLINE") == nullptr;
+      side_stats = !h.comm.active() && dbg_env("SAPCA_MASK_STATS_INLINE") == nullptr;
       double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
       SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
       if (!side_stats) {
@@ -324,7 +324,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   bool at_direct = false;
   if constexpr (sizeof(T) == 4) {
     if (try_direct) {
-      if (getenv("SAPCA_PREPARE_ASIDE_FIRST") && aside.joinable()) {   // timing runs: A's format alone on the chip, then A^T's
+      if (dbg_env("SAPCA_PREPARE_ASIDE_FIRST") && aside.joinable()) {   // timing runs: A's format alone on the chip, then A^T's
         aside.join();
         SAPCA_HIP(hipStreamSynchronize(h.stream2));
       }
@@ -403,7 +403,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     // unmasked: the statistics and the format builder read the sort's packed rows directly and the
     // unpack pass into (at_idx, at_val) is skipped (done lazily below if the row kernel has to take over)
     k::transpose_csr(A, at_ptr, at_idx, at_val, h.scratch, s, at_tile_major ? k::tiled_tile_count(m, tiled_ldp_words) : 0,
-                     (at_tile_major && !masked && getenv("SAPCA_AT_UNPACK") == nullptr) ? &at_packed : nullptr);
+                     (at_tile_major && !masked && dbg_env("SAPCA_AT_UNPACK") == nullptr) ? &at_packed : nullptr);
     At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = at_idx; At.val = at_val;
   }
 
@@ -839,7 +839,7 @@ void Engine<T>::fit_randomized(H& h) {
   // f64 instantiation keeps the QR + Jacobi route below.  Saves two CholeskyQR passes over the n x l
   // panel and 0.4 ms of host time per fit.
   int info_host = 0;
-  const bool gram_route = sizeof(T) == 4 && getenv("SAPCA_SMALL_SVD_QR") == nullptr;
+  const bool gram_route = sizeof(T) == 4 && dbg_env("SAPCA_SMALL_SVD_QR") == nullptr;
   if (gram_route) {
     Scope sc(h, C_SMALL);
     double* G = small;
@@ -1227,7 +1227,7 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
         // the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (spmm_dq.hip)
-        if (center && top && h.opt.spmm_variant != 1 && !h.q3_cancels && getenv("SAPCA_Q3_ROWKERNEL") == nullptr) {
+        if (center && top && h.opt.spmm_variant != 1 && !h.q3_cancels && dbg_env("SAPCA_Q3_ROWKERNEL") == nullptr) {
           float* W2 = h.scratch2.as<float>((size_t)n_used * ldk);
           float* tmp = h.panel_y.as<float>((size_t)m * std::max(k, 1));
           done = k::q3_projection_dq(Au, *top, W, ldk, mu, W2, tmp, d_out, k, s);

@@ -89,6 +89,9 @@ void log1p_values(T* values, int64_t nnz, hipStream_t s);
 template <typename T>
 void row_stats(const CsrView<T>& A, double* sum, double* sumsq, T* minv, T* maxv, hipStream_t s);
 
+// dst[0 .. bytes) = src[0 .. bytes) by a 16-byte-per-lane streaming kernel (the attainable-HBM-rate probe of sapca_measure_copy_gbs)
+void stream_copy16(const void* src, void* dst, int64_t bytes, hipStream_t s);
+
 // ---- spmm.hip --------------------------------------------------------------------------
 // Y[r][j] = sum_e val_e X[col_e][j] - cvec[j]   for j < ncols; X has leading dimension ldx
 // (multiple of 16/sizeof(T)... see spmm.hip), Y leading dimension ldy.  cvec may be null.

@@ -378,8 +378,8 @@ inline unsigned grid1(int64_t n, int block = 256, int64_t cap = 1 << 30) {
 enum SpmvKind { SPMV_ROW = 0, SPMV_LDSX, SPMV_SLICE_GRID, SPMV_SLICED };
 template <typename T>
 SpmvKind spmv_plan(const CsrView<T>& A, bool has_scratch, int* slice_out = nullptr, int* nslices_out = nullptr) {
-  static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
-  static const bool no_grid = getenv("SAPCA_SPMV_NO_SLICE_GRID") != nullptr;
+  static const bool no_lds = dbg_env("SAPCA_SPMV_NO_LDS") != nullptr;
+  static const bool no_grid = dbg_env("SAPCA_SPMV_NO_SLICE_GRID") != nullptr;
   const size_t xbytes = (size_t)A.cols * sizeof(double);
   if (A.rows == 0 || no_lds) return SPMV_ROW;
   if (xbytes <= 150 * 1024 && A.rows >= 4096) return SPMV_LDSX;
@@ -404,7 +404,7 @@ __global__ void narrow_idx16_kernel(const int32_t* __restrict__ idx, int64_t cou
 // the 2-byte index copy an operator's Lanczos kernel reads (nullptr: that kernel takes the 4-byte columns)
 template <typename T>
 const uint16_t* spmv_narrow_indices(const CsrView<T>& A, bool has_scratch, DevBuf& buf, hipStream_t s) {
-  static const bool off = getenv("SAPCA_SPMV_IDX32") != nullptr;
+  static const bool off = dbg_env("SAPCA_SPMV_IDX32") != nullptr;
   int slice = 0, nslices = 0;
   const SpmvKind kind = spmv_plan(A, has_scratch, &slice, &nslices);
   if (off || A.nnz == 0 || (kind != SPMV_LDSX && kind != SPMV_SLICE_GRID)) return nullptr;
@@ -423,7 +423,7 @@ void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s,
   if (ymax_done) *ymax_done = false;   // (only the kernel with x in LDS gathers max |y| on the way)
   if (A.rows == 0) return;
   const size_t xbytes = (size_t)A.cols * sizeof(double);
-  static const bool no_lds = getenv("SAPCA_SPMV_NO_LDS") != nullptr;
+  static const bool no_lds = dbg_env("SAPCA_SPMV_NO_LDS") != nullptr;
   if (!no_lds && xbytes <= 150 * 1024 && A.rows >= 4096) {
     static LdsAttrState attr, attr16;   // one per instantiation of this function template
     if (idx16) {
@@ -441,7 +441,7 @@ void spmv_launch(const CsrView<T>& A, const double* x, double* y, hipStream_t s,
     const int nslices = (int)((A.cols + max_slice - 1) / max_slice);
     const int slice = (int)((A.cols + nslices - 1) / nslices);
     // (slice, row group) grid when the caller lends a buffer for the per-slice partial sums
-    static const bool no_grid = getenv("SAPCA_SPMV_NO_SLICE_GRID") != nullptr;
+    static const bool no_grid = dbg_env("SAPCA_SPMV_NO_SLICE_GRID") != nullptr;
     if (scratch && !no_grid && nslices > 1) {
       const int64_t groups_one_round = std::max<int64_t>(1, 256 / nslices);
       const int rows_per_group = (int)std::min<int64_t>(SLICE_WAVES * WAVE, (A.rows + groups_one_round - 1) / groups_one_round);
@@ -569,7 +569,7 @@ void lanczos_fit(sapca_handle_s& h) {
   // the bottom row of the eigenvector matrix (the error bounds need nothing else), so while T is small every step is
   // checked and no step is run past convergence; as T grows the checks thin out.  SAPCA_LANCZOS_CHECK=<n> fixes the
   // interval (experiments).
-  static const int check_env = getenv("SAPCA_LANCZOS_CHECK") ? atoi(getenv("SAPCA_LANCZOS_CHECK")) : 0;
+  static const int check_env = dbg_env("SAPCA_LANCZOS_CHECK") ? atoi(dbg_env("SAPCA_LANCZOS_CHECK")) : 0;
   auto check_due = [&](int64_t j) {
     const int every = check_env > 0 ? check_env : j <= 64 ? 1 : j <= 128 ? 2 : j <= 256 ? 4 : 8;
     return j % every == 0;

@@ -504,7 +504,7 @@ void transpose_csr(const CsrView<T>& A, int64_t* t_ptr, int32_t* t_idx, T* t_val
     return;
   }
   if constexpr (sizeof(T) == 8) {
-    static const bool gather_route = getenv("SAPCA_TRANSPOSE_GATHER") != nullptr;
+    static const bool gather_route = dbg_env("SAPCA_TRANSPOSE_GATHER") != nullptr;
     if (!gather_route) {
       const bool k16 = bits <= 16;
       size_t sb = 0;

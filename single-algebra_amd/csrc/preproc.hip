@@ -127,6 +127,21 @@ void normalize_csr(const CsrView<T>& A, T* values, const double* d_sums, double 
   SAPCA_HIP(hipGetLastError());
 }
 
+// A 16-byte-per-lane streaming copy: what this device's HBM delivers to a kernel of this library (read + write), the
+// attainable figure bench.py reports beside the 8 TB/s of the data sheet.
+__global__ void __launch_bounds__(256) copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+void stream_copy16(const void* src, void* dst, int64_t bytes, hipStream_t s) {
+  const int64_t n16 = bytes / 16;
+  if (n16 == 0) return;
+  // (8 workgroups of 256 threads per CU: every lane keeps a few 16-byte loads in flight)
+  hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, s, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+  SAPCA_HIP(hipGetLastError());
+}
+
 template <typename T>
 void log1p_values(T* values, int64_t nnz, hipStream_t s) {
   if (nnz == 0) return;

@@ -224,7 +224,7 @@ void launch_rowgather(const CsrView<T>& A, const T* X, int ldx, T* Y, int ldy, i
   int64_t blocks = (A.rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
-  static const bool per_entry = getenv("SAPCA_ROWGATHER_PER_ENTRY") != nullptr;   // (experiments: the kernel without the DPP feed)
+  static const bool per_entry = dbg_env("SAPCA_ROWGATHER_PER_ENTRY") != nullptr;   // (experiments: the kernel without the DPP feed)
   if constexpr (LPR >= 16) {
     if (!per_entry) {
       if (shift)

@@ -269,8 +269,8 @@ spmm_dq_f64_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restr
 
 bool dq_build_tables(TiledOp& op, TiledBuffers& buf, hipStream_t s) {
   op.dq = false;
-  static const bool off = getenv("SAPCA_NO_DQ") != nullptr;
-  static const bool off64 = getenv("SAPCA_NO_DQ_F64") != nullptr;   // f64 fits on round 1's staged-entry sweep (A/B runs)
+  static const bool off = dbg_env("SAPCA_NO_DQ") != nullptr;
+  static const bool off64 = dbg_env("SAPCA_NO_DQ_F64") != nullptr;   // f64 fits on round 1's staged-entry sweep (A/B runs)
   if (off || !op.valid || op.fmt != 1 || op.ldp != 64 || op.tile_bytes != DQ_TILE_BYTES) return false;
   if (op.elem == 8) {
     if (off64 || op.block_rows != 64 * DQ_F64_RG) return false;

@@ -1963,7 +1963,7 @@ void float_blocks(int64_t n, int64_t nrb, std::vector<int32_t>& blk, float& scal
 // rows per block of the DPP-fed sweep's operators, and the natural (unsorted) partition of `op_rows` rows: block count and
 // the split of the tile range over workgroups
 int dq_block_rows(int64_t op_rows) {
-  static const int dq_rows_env = getenv("SAPCA_DQ_BLOCK_ROWS") ? atoi(getenv("SAPCA_DQ_BLOCK_ROWS")) : 0;
+  static const int dq_rows_env = dbg_env("SAPCA_DQ_BLOCK_ROWS") ? atoi(dbg_env("SAPCA_DQ_BLOCK_ROWS")) : 0;
   return dq_rows_env == 512 || dq_rows_env == 1024 ? dq_rows_env : (op_rows >= 1024 * 16 ? 1024 : 512);
 }
 void natural_partition(int64_t op_rows, int nct, int block_rows, int64_t& nrb, int& nsplit) {
@@ -1974,7 +1974,7 @@ void natural_partition(int64_t op_rows, int nct, int block_rows, int64_t& nrb, i
   } else {
     // few row blocks (A^T): split the tile range so that (blocks x splits) lands just under a
     // multiple of the 256 CUs -- one workgroup per CU per round, no half-empty last round
-    static const int split_wgs_env = getenv("SAPCA_SPLIT_WGS") ? atoi(getenv("SAPCA_SPLIT_WGS")) : 0;
+    static const int split_wgs_env = dbg_env("SAPCA_SPLIT_WGS") ? atoi(dbg_env("SAPCA_SPLIT_WGS")) : 0;
     // 1024-row blocks fill a CU's LDS and registers alone: one workgroup per CU; the others run two per CU
     const int64_t split_wgs = split_wgs_env > 0 ? split_wgs_env : (block_rows > 512 ? 256 : 512);
     nsplit = (int)std::min<int64_t>(nct, std::max<int64_t>(1, split_wgs / nrb));
@@ -1996,7 +1996,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   if (S.rows == 0 || S.cols == 0 || S.nnz == 0) return false;
   // the operator is S, or S^T built straight from S (quad format only)
   const int64_t op_rows = transposed ? S.cols : S.rows, op_cols = transposed ? S.rows : S.cols;
-  static const int fmt_env = getenv("SAPCA_TILED_FMT") ? atoi(getenv("SAPCA_TILED_FMT")) : 1;
+  static const int fmt_env = dbg_env("SAPCA_TILED_FMT") ? atoi(dbg_env("SAPCA_TILED_FMT")) : 1;
   const bool quad = fmt_env == 1 || !f32;   // 1: a row per 16-lane group (default); 0: two half-waves per row
   int tile_bytes = quad ? Q_TILE_BYTES : TILE_BYTES;
   int tc = tile_bytes / (ldp * 4);
@@ -2007,13 +2007,13 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   const int maskw = (Q_TILE_BYTES / (ldp * 4) + 31) / 32;   // only the transposed builder uses it (default split)
   // row blocks of <= 512 rows.  With enough rows the block count is a multiple of the 256 CUs (every
   // CU runs the same number of workgroups); with few rows (A^T) the tile range is split instead.
-  static const int slots_env = getenv("SAPCA_TILED_SLOTS") ? atoi(getenv("SAPCA_TILED_SLOTS")) : 2;
+  static const int slots_env = dbg_env("SAPCA_TILED_SLOTS") ? atoi(dbg_env("SAPCA_TILED_SLOTS")) : 2;
   const int slots = (ldp == 64 && slots_env == 4) ? 4 : 2;
   const int waves = quad ? QWAVES : waves_for(slots);
   // (the DPP-fed sweep double-buffers the default 80 KiB tile and holds 8 or 16 row slots per lane group: f32 operators
   // with 64-column tiles keep that split, and take 1024-row blocks -- half the tile refills and barriers per entry --
   // when the operator has at least 16 of them (A^T of a tall matrix: the tile range is split over workgroups instead))
-  const bool dq_candidate = f32 && quad && ldp == 64 && getenv("SAPCA_NO_DQ") == nullptr;
+  const bool dq_candidate = f32 && quad && ldp == 64 && dbg_env("SAPCA_NO_DQ") == nullptr;
   const int block_rows = dq_candidate ? dq_block_rows(op_rows)
                          : quad ? QWAVES * QGROUPS * q_rows_per_group(ldp)
                                 : waves * ((slots == 2 && ldp == 128) ? RW / 2 : (slots == 2 ? RW2 : RW));
@@ -2025,8 +2025,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // in the smaller staging area; operators fed by the tile-major transposition keep the default split
   // (their tile count is fixed before the transposition runs)
   // (f64 operators keep the default split too: the f64 DPP-fed sweep double-buffers the 80 KiB tile)
-  const bool dq64_candidate = !f32 && quad && getenv("SAPCA_NO_DQ") == nullptr && getenv("SAPCA_NO_DQ_F64") == nullptr;
-  if (quad && !transposed && !rows_tile_major && allow_big_tile && !dq_candidate && !dq64_candidate && getenv("SAPCA_TILE_DEFAULT") == nullptr) {
+  const bool dq64_candidate = !f32 && quad && dbg_env("SAPCA_NO_DQ") == nullptr && dbg_env("SAPCA_NO_DQ_F64") == nullptr;
+  if (quad && !transposed && !rows_tile_major && allow_big_tile && !dq_candidate && !dq64_candidate && dbg_env("SAPCA_TILE_DEFAULT") == nullptr) {
     const int tcb = Q_TILE_BYTES_BIG / (ldp * 4);
     const double est = 1.3 * (double)S.nnz / ((double)nrb * std::ceil((double)op_cols / tcb));
     if (est <= 0.78 * (q_stage_bytes(Q_TILE_BYTES_BIG) / (int)sizeof(E) - WAVE)) {
@@ -2062,12 +2062,12 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // detection rate).  Blocks are cut from the sorted order with about equal entry counts (at most 512 rows).
   uint32_t* d_perm = nullptr;
   std::vector<uint32_t> sorted_len;
-  bool sort_rows = quad && !transposed && getenv("SAPCA_NO_ROWSORT") == nullptr;
+  bool sort_rows = quad && !transposed && dbg_env("SAPCA_NO_ROWSORT") == nullptr;
   // page-locked staging of this builder: [0] slots of the natural quads, [1..2] largest chunk | total, then the block table
   int64_t* pinned = static_cast<int64_t*>(buf.host.ensure((size_t)(8 + 65536 + 2) * sizeof(int64_t)));
   bool speculate = false;
   bool rows_in_disorder = false;   // (bucket route: the source's rows were found unsorted by the histogram pass)
-  if (sort_rows && getenv("SAPCA_ROWSORT_ALWAYS") == nullptr) {
+  if (sort_rows && dbg_env("SAPCA_ROWSORT_ALWAYS") == nullptr) {
     // homogeneous rows pad little in their natural order: skip the sort (0.2 ms per operator at C2) unless the
     // natural quads would hold 10 % more slots than entries.  The count comes back with the chunk sizes below -- the
     // natural order is assumed until then (one wait for the device instead of two); a matrix that needs the sort
@@ -2185,7 +2185,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     }
     max_chunk = host[0];
     total = host[1];
-    if (getenv("SAPCA_DEBUG"))
+    if (dbg_env("SAPCA_DEBUG"))
       fprintf(stderr, "sapca: build_tiled%s rows %lld cols %lld nrb %lld nct %d split %d max_chunk %lld (cap %d) total %lld\n",
               transposed ? " (transposed source)" : "", (long long)op_rows, (long long)op_cols, (long long)nrb, nct, nsplit,
               (long long)max_chunk, stage_cap, (long long)total);
@@ -2232,7 +2232,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   // the direct fill over a zeroed buffer
   // f64 entries are 16 bytes: the LDS image holds QF_CAP_MIN of them (64 KiB), two workgroups per CU
   const int qf_cap_max = f32 ? QF_CAP_MAX : QF_CAP_MIN;
-  const bool staged_fill = quad && !transposed && !rows_tile_major && getenv("SAPCA_FILL_DIRECT") == nullptr &&
+  const bool staged_fill = quad && !transposed && !rows_tile_major && dbg_env("SAPCA_FILL_DIRECT") == nullptr &&
                            (double)total <= 0.93 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;   // (a quad above the image takes the direct route inside the kernel)
   const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
@@ -2257,7 +2257,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     // (rows of A whose columns do not ascend -- include/sapca.h promises wrong numbers for them, not stray accesses: the run
     //  ends the histogram recorded are meaningless then, the bucket route needs none)
     const bool gather = direct->bnd != nullptr && d_perm == nullptr && nrb == direct->nrb_nat && !rows_in_disorder &&
-                        getenv("SAPCA_AT_BUCKETS") == nullptr;
+                        dbg_env("SAPCA_AT_BUCKETS") == nullptr;
     const size_t a_col = round_up((size_t)op_rows * sizeof(uint32_t), 256), a_bucket = gather ? 0 : round_up((size_t)A.nnz * sizeof(uint2), 256);
     const size_t a_part = direct->stats ? round_up((size_t)nct * op_rows * sizeof(double), 256) : 0;
     const size_t a_scan = round_up(scan_bytes + 256, 256);
@@ -2289,7 +2289,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     hipLaunchKernelGGL(tquad_fill_kernel, dim3((unsigned)nchunks), dim3(TQ_THREADS), 0, s, S.ptr, S.idx, S.val, d_rank, d_seg,
                        S.rows, d_blk, (int)nrb, nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   else if (runs_fill) {
-    const int seg_lds_max = getenv("SAPCA_RUNS_SEG_LDS_MAX") ? atoi(getenv("SAPCA_RUNS_SEG_LDS_MAX")) : 1024;   // tiles; above: bounds from global memory
+    const int seg_lds_max = dbg_env("SAPCA_RUNS_SEG_LDS_MAX") ? atoi(dbg_env("SAPCA_RUNS_SEG_LDS_MAX")) : 1024;   // tiles; above: bounds from global memory
     if (nct <= seg_lds_max)
       hipLaunchKernelGGL(quad_fill_runs_kernel<true>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                          (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, packed_rows, d_seg, d_blk, d_perm, nct,
@@ -2314,7 +2314,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     (void)lds; (void)run_global; (void)d_rank;
     if (runs_fill) {
       // rows grouped by tile (the tile-major transposition): a quad's run in a tile is contiguous in its rows
-      const int seg_lds_max = getenv("SAPCA_RUNS_SEG_LDS_MAX") ? atoi(getenv("SAPCA_RUNS_SEG_LDS_MAX")) : 1024;
+      const int seg_lds_max = dbg_env("SAPCA_RUNS_SEG_LDS_MAX") ? atoi(dbg_env("SAPCA_RUNS_SEG_LDS_MAX")) : 1024;
       if (nct <= seg_lds_max)
         hipLaunchKernelGGL((quad_fill_runs_kernel<true, double>), dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
                            (size_t)4 * (nct + 1) * sizeof(int32_t), s, S.ptr, S.idx, S.val, (const uint64_t*)nullptr, d_seg, d_blk, d_perm, nct,
@@ -2350,7 +2350,7 @@ bool build_tiled(const CsrView<double>& S, int ldp, TiledOp& op, TiledBuffers& b
 bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledBuffers& buf, int64_t* at_ptr, double* stats,
                            DevBuf& scratch, hipStream_t s) {
   op = TiledOp();
-  const bool off = getenv("SAPCA_AT_SORT") != nullptr;   // A/B: the transposition (radix sort) route
+  const bool off = dbg_env("SAPCA_AT_SORT") != nullptr;   // A/B: the transposition (radix sort) route
   if (off || ldp != 64 || A.rows == 0 || A.cols == 0 || A.nnz == 0 || A.cols > ATD_MAX_COLS || A.rows >= (1 << 24)) return false;
   const int64_t m = A.rows, n = A.cols;
   const int tc = Q_TILE_BYTES / (ldp * 4);
@@ -2365,7 +2365,7 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   int nsplit_nat = 1;
   natural_partition(n, nct, dq_block_rows(n), nrb_nat, nsplit_nat);
   int64_t* bnd = nullptr;
-  if (getenv("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096) {
+  if (dbg_env("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096) {
     const size_t bytes = (size_t)(nrb_nat + 1) * (size_t)nct * tc * sizeof(int64_t);
     bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
     SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
@@ -2409,7 +2409,7 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
   SAPCA_CHECK(op.valid && op.elem == 4, SAPCA_ERR_ARG, "tiled sweep: operator not built");
   SAPCA_CHECK(ldx == op.ldp || (op.fmt == 1 && op.ldp == 64 && ldx % 64 == 0), SAPCA_ERR_ARG,
               "tiled sweep: panel leading dimension does not match the operator's tile geometry");
-  static const int mode = getenv("SAPCA_TILED_MODE") ? atoi(getenv("SAPCA_TILED_MODE")) : 0;  // ablation switches (debug)
+  static const int mode = dbg_env("SAPCA_TILED_MODE") ? atoi(dbg_env("SAPCA_TILED_MODE")) : 0;  // ablation switches (debug)
   // A 128-wide panel over the 64-wide tile geometry goes through in two column passes: twice the entry
   // traffic, but a tile holds twice the panel rows of the 128-wide geometry (half the tiles, less quad
   // padding, chunks that amortise their refill) -- what keeps wide panels on sparse operators (C5) staged.
@@ -2429,7 +2429,7 @@ void spmm_tiled(const TiledOp& op, const float* X, int ldx, float* Y, int ldy, i
       ldo = op.ldp;
       nc = op.ldp;
     }
-    static const bool force_staged = getenv("SAPCA_SWEEP_STAGED") != nullptr;   // A/B: the staged-entry quad sweep
+    static const bool force_staged = dbg_env("SAPCA_SWEEP_STAGED") != nullptr;   // A/B: the staged-entry quad sweep
     // (blocks of more than 512 rows exist only for the DPP-fed sweep: the switches below do not apply to them)
     const bool staged_ok = op.block_rows <= 512 && op.max_chunk <= (int64_t)(q_stage_bytes(op.tile_bytes) / 8 - WAVE);
     SAPCA_CHECK(op.fmt != 1 || staged_ok || dq_usable(op, ldx), SAPCA_ERR_ARG, "tiled sweep: this operator needs the DPP-fed sweep");
@@ -2546,7 +2546,7 @@ void spmm_tiled(const TiledOp& op, const double* X, int ldx, double* Y, int ldy,
 }
 
 int tiled_geometry(int l) {
-  static const bool wide = getenv("SAPCA_TILED_GEOM128") != nullptr;   // the 128-wide tile geometry for l > 64 (one pass)
+  static const bool wide = dbg_env("SAPCA_TILED_GEOM128") != nullptr;   // the 128-wide tile geometry for l > 64 (one pass)
   return (l > 64 && wide) ? 128 : 64;
 }
 

@@ -8,6 +8,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAPCA_LIB_PATH points at another build of the same library (kernel experiments, tools/abl_build.sh)
 LIB_PATH = os.environ.get("SAPCA_LIB_PATH") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libsapca.so"))
+# the variant that reads the SAPCA_* experiment / route switches (csrc/switches.h; the release library reads none of them)
+DEBUG_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libsapca_dbg.so"))
 
 OK, ERR_ARG, ERR_MASK_LEN, ERR_NOT_FITTED, ERR_SVD, ERR_HIP, ERR_COMM, ERR_NOMEM = range(8)
 LANCZOS, RANDOM = 0, 1
@@ -59,7 +61,7 @@ _PLAIN = [
     "sapca_set_mask", "sapca_get_dims", "sapca_get_total_variance", "sapca_get_mask_index_maps",
     "sapca_get_timings", "sapca_partition_rows", "sapca_comm_unique_id", "sapca_comm_rccl_available", "sapca_comm_init_rank",
     "sapca_comm_set_callback", "sapca_comm_allreduce", "sapca_comm_abort", "sapca_comm_async_error", "sapca_comm_has_side_lane",
-    "sapca_upload_values_changed", "sapca_multi_fit_resident", "sapca_multi_resident_shard",
+    "sapca_upload_values_changed", "sapca_measure_copy_gbs", "sapca_multi_fit_resident", "sapca_multi_resident_shard",
     "sapca_multi_create", "sapca_multi_destroy", "sapca_multi_last_error", "sapca_multi_n_devices", "sapca_multi_member",
     "sapca_multi_uses_rccl", "sapca_multi_set_mask",
 ]
@@ -90,7 +92,26 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C single-algebra_amd` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    _lib = _open(LIB_PATH)
+    return _lib
+
+
+_debug_lib = None
+
+
+def load_debug():
+    """The -DSAPCA_DEBUG_SWITCHES build of the same sources (make debug): for tests and tools that steer routes through
+    SAPCA_* environment variables.  A second library instance beside the release one (its own handles: objects do not cross)."""
+    global _debug_lib
+    if _debug_lib is None:
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise ImportError(f"{DEBUG_LIB_PATH} is missing: build it with `make -C single-algebra_amd debug`")
+        _debug_lib = _open(DEBUG_LIB_PATH)
+    return _debug_lib
+
+
+def _open(path):
+    lib = C.CDLL(path)
     lib.sapca_last_error.restype = C.c_char_p
     lib.sapca_last_error.argtypes = [C.c_void_p]
     lib.sapca_create.argtypes = [C.POINTER(Options), C.POINTER(C.c_void_p)]
@@ -108,11 +129,13 @@ def load():
     lib.sapca_multi_n_devices.argtypes = [C.c_void_p]
     lib.sapca_multi_n_devices.restype = C.c_uint32
     lib.sapca_multi_uses_rccl.argtypes = [C.c_void_p]
-    lib.sapca_multi_fit_resident.argtypes = [C.c_void_p]
-    lib.sapca_comm_abort.argtypes = [C.c_void_p]
-    lib.sapca_comm_async_error.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
-    lib.sapca_comm_has_side_lane.argtypes = [C.c_void_p]
-    _lib = lib
+    if hasattr(lib, "sapca_comm_abort"):   # (ABI 4; an older build loaded through SAPCA_LIB_PATH for an A/B run lacks them)
+        lib.sapca_multi_fit_resident.argtypes = [C.c_void_p]
+        lib.sapca_comm_abort.argtypes = [C.c_void_p]
+        lib.sapca_comm_async_error.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        lib.sapca_comm_has_side_lane.argtypes = [C.c_void_p]
+    if hasattr(lib, "sapca_measure_copy_gbs"):
+        lib.sapca_measure_copy_gbs.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
     return lib
 
 

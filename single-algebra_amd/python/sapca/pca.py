@@ -268,6 +268,24 @@ class _Estimator:
         self._cb = L.ALLREDUCE_FN(fn)     # keep alive
         L.check(self._h, L.load().sapca_comm_set_callback(self._h, C.c_uint32(nranks), C.c_uint32(rank), self._cb, None))
 
+    def comm_abort(self):
+        """End every collective of this handle (a peer rank failed): sapca_comm_abort; callable from another thread."""
+        L.check(self._h, L.load().sapca_comm_abort(self._h))
+
+    def comm_async_error(self):
+        st = C.c_int32(0)
+        L.check(self._h, L.load().sapca_comm_async_error(self._h, C.byref(st)))
+        return int(st.value)
+
+    def comm_has_side_lane(self):
+        return bool(L.load().sapca_comm_has_side_lane(self._h))
+
+    def measure_copy_gbs(self, nbytes=1 << 30, reps=5):
+        """GB/s (read + write) of the library's 16-byte-per-lane streaming copy on this handle's device"""
+        g = C.c_double(0.0)
+        L.check(self._h, L.load().sapca_measure_copy_gbs(self._h, C.c_uint64(nbytes), C.c_uint32(reps), C.byref(g)))
+        return float(g.value)
+
 
 def _note_dtype(est, x):
     if isinstance(x, DeviceCsr):

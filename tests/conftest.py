@@ -22,3 +22,15 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+@pytest.fixture
+def debug_switches(monkeypatch):
+    """Route tests.  The SAPCA_* experiment switches exist only in the -DSAPCA_DEBUG_SWITCHES build of the library
+    (single-algebra_amd/csrc/switches.h: the release build reads none of them, so a stray variable in a caller's process
+    cannot change a route).  For the duration of the test every call of the Python layer goes to that build
+    (lib/libsapca_dbg.so: same sources, same kernels), beside the release library the other tests use."""
+    from sapca import _lib as L
+    L.load()
+    monkeypatch.setattr(L, "_lib", L.load_debug())
+    yield

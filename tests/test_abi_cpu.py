@@ -153,3 +153,28 @@ def test_generated_sweep_loop_is_what_its_generator_writes(tmp_path):
     assert r.returncode == 0, r.stderr
     committed = open(os.path.join(ROOT, "single-algebra_amd", "csrc", "spmm_dq2_gen.h")).read()
     assert out.read_text() == committed, "spmm_dq2_gen.h is stale: run python tools/gen_spmm_dq2.py"
+
+
+def test_release_library_reads_no_experiment_switches():
+    """csrc/switches.h: the SAPCA_* route / layout switches exist only in the -DSAPCA_DEBUG_SWITCHES variant.  The release
+    library does not even carry their names; what it does read is listed in switches.h (two deployment escapes)."""
+    import glob
+    src = os.path.join(ROOT, "single-algebra_amd", "csrc")
+    sites = []
+    for f in glob.glob(os.path.join(src, "*")):
+        for i, line in enumerate(open(f, errors="replace"), 1):
+            if re.search(r"\bgetenv\s*\(", line):
+                sites.append((os.path.basename(f), i, line.strip()))
+    names = sorted(set(re.findall(r'getenv\("(SAPCA_\w+)"\)', " ".join(s[2] for s in sites))))
+    assert names == ["SAPCA_AT_OVERLAP", "SAPCA_MULTI_INPROCESS"], names
+    assert len(sites) <= 8, sites
+    rel = open(L.LIB_PATH, "rb").read()
+    for name in (b"SAPCA_TILED_FMT", b"SAPCA_AT_NATURAL", b"SAPCA_TRANSPOSE_GATHER", b"SAPCA_MASK_TRANSPOSE_FIRST", b"SAPCA_COMM_FORCE_RCCL"):
+        assert name not in rel, f"the release library carries the switch {name.decode()}"
+    assert b"SAPCA_AT_OVERLAP" in rel
+    if os.path.exists(L.DEBUG_LIB_PATH):
+        dbg = open(L.DEBUG_LIB_PATH, "rb").read()
+        assert b"SAPCA_TILED_FMT" in dbg and b"SAPCA_COMM_FORCE_RCCL" in dbg
+        lib = L.load_debug()
+        for name in L.EXPORTED_SYMBOLS:
+            assert hasattr(lib, name), name

@@ -66,8 +66,10 @@ def _worker_straddle(rank, world, port, tmpdir):
     kernels, and (before the panel leading dimension was pinned for sharded fits) different all-reduce sizes."""
     import torch.distributed as dist
     import sapca
+    from sapca import _lib as L
     from sapca import dist as sdist
     from sapca import synth
+    L._lib = L.load_debug()   # (the entry floor is a switch of the -DSAPCA_DEBUG_SWITCHES build: csrc/switches.h)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SAPCA_TILED_MIN_ENTRIES="400000")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -114,7 +116,7 @@ def test_two_rank_row_sharded_fit(tmp_path, method):
 
 
 @pytest.mark.gpu
-def test_rccl_binding_with_a_one_rank_communicator(monkeypatch):
+def test_rccl_binding_with_a_one_rank_communicator(debug_switches, monkeypatch):
     """One GPU cannot host two RCCL ranks, but a one-rank communicator still exercises the library's own
     RCCL binding (dlopen, ncclCommInitRank by-value id, ncclAllReduce on the library stream) at every
     all-reduce site of a fit; the result must equal the fit without a communicator."""
@@ -157,7 +159,7 @@ def test_rccl_binding_with_a_one_rank_communicator(monkeypatch):
     np.testing.assert_allclose(lz.singular_values_(np.float64), lz_ref.singular_values_(np.float64), rtol=1e-12)
 
 
-def test_rccl_communicator_can_be_aborted_and_rebuilt(monkeypatch):
+def test_rccl_communicator_can_be_aborted_and_rebuilt(debug_switches, monkeypatch):
     """The built-in RCCL binding on a one-rank communicator (SAPCA_COMM_FORCE_RCCL=1 routes every all-reduce site through
     ncclAllReduce): the side stream gets its own communicator (ncclCommSplit), sapca_comm_abort ends the communicators --
     the next fit fails at once with SAPCA_ERR_COMM instead of entering a collective -- and a new sapca_comm_init_rank

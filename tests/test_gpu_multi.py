@@ -86,7 +86,7 @@ def test_a_failing_shard_fails_the_call_and_releases_its_peers():
                           .svd_method(SVDMethod.Random(3, 1)).build(), [0, 0]).fit(B)
 
 
-def test_transposed_sweep_in_two_pieces_with_the_first_all_reduce_behind_the_second(monkeypatch):
+def test_transposed_sweep_in_two_pieces_with_the_first_all_reduce_behind_the_second(debug_switches, monkeypatch):
     """the n x l panel of an A^T sweep is the one bandwidth-relevant collective of a sharded fit.  Where the
     operator allows it (DPP-fed sweep, rows in natural order) the sweep runs in two pieces of its output rows and the first
     piece's all-reduce runs on a side stream behind the second piece's sweep; the members agree on the cut (their own row

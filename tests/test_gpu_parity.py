@@ -217,7 +217,7 @@ def test_row_kernel_chunk_boundaries(session, dtype, l, tol):
 
 
 @pytest.mark.parametrize("dtype,k,tol", [(np.float64, 30, 1e-10), (np.float64, 40, 1e-10), (np.float32, 40, 5e-5)])
-def test_masked_projection_row_kernel_with_long_rows(monkeypatch, dtype, k, tol):
+def test_masked_projection_row_kernel_with_long_rows(debug_switches, monkeypatch, dtype, k, tol):
     """quirk Q3 through the row kernel with the mean folded in (value - mu[column] per stored, kept entry), rows of every
     length around the chunk sizes, 16 and 32 lanes per panel row; against the oracle's entry loop"""
     monkeypatch.setenv("SAPCA_Q3_ROWKERNEL", "1")
@@ -268,6 +268,15 @@ def test_omega_generator_matches_host_function(session):
 
 
 # ------------------------------------------------------------------ G4: full randomized fit
+# Projection against the ORACLE's components at production size.  The two sides project with their own components: what
+# separates them is (i) the f32 rounding of the sweeps (a row holds ~600 entries; Q2 multiplies every feature by its
+# stored-entry count, up to 6e3 -- the same factor on both sides) and (ii) the rotation of neighbouring components inside the
+# subspace both sides agree on to 1e-4 rad (adjacent singular values of the gapped generator differ by 1.1 %: an error of
+# 1e-6 in the small SVD turns a pair by 1e-4).  Both are of order 1e-4 of the largest score: the bound is 2e-4, the one the
+# small random configurations hold (measured, round 4: all four production-size cases pass at 1e-4 -- gpurun_out/r4_oracle_tests_*).
+PROJ_ATOL = float(os.environ.get("SAPCA_TEST_PROJ_ATOL", "2e-4"))
+
+
 def _builder(k, p, q, norm=PIN.QR, **kw):
     b = sapca.SparsePCABuilder.new().n_components(k).random_seed(42).svd_method(SVDMethod.Random(p, q, norm))
     for key, v in kw.items():
@@ -422,7 +431,7 @@ def test_masked_randomized_fit_vs_oracle(dtype, ang):
     assert np.array_equal(cols, want.cols_to_use) and np.array_equal(o2m, want.orig_to_masked)
 
 
-def test_masked_projection_through_the_sweep_with_stored_zeros(monkeypatch):
+def test_masked_projection_through_the_sweep_with_stored_zeros(debug_switches, monkeypatch):
     """quirk Q3 through the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (the second reads every stored
     non-zero value as 1) plus the stored zeros by hand -- here a few hundred stored +0.0 / -0.0 entries, which the format
     cannot tell from its padding.  Against the oracle's entry loop, and against the row kernel on shifted values."""
@@ -740,7 +749,7 @@ def test_production_dispatch_against_the_oracle():
     ratio = (sing[:k].astype(np.float64) ** 2) / (sing[:k].astype(np.float64) ** 2).sum()
     np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), ratio, atol=1e-6)
     want = orc.transform_sparse(ptr, idx, val, m, n, comps, mean, True)
-    np.testing.assert_allclose(t, want, atol=2e-3 * np.abs(want).max())
+    np.testing.assert_allclose(t, want, atol=PROJ_ATOL * np.abs(want).max())
 
 
 def test_c2_at_full_size_against_the_oracle():
@@ -771,7 +780,7 @@ def test_c2_at_full_size_against_the_oracle():
     X = sp.csr_matrix((val[take], idx[take], sub_ptr), shape=(len(rows), n))
     W = (comps[:k].astype(np.float64) * cnt[None, :]).T
     want = X @ W - (mean.astype(np.float64) @ W)[None, :]
-    np.testing.assert_allclose(t[torch.as_tensor(rows, device=t.device)].cpu().numpy(), want, atol=2e-3 * np.abs(want).max())
+    np.testing.assert_allclose(t[torch.as_tensor(rows, device=t.device)].cpu().numpy(), want, atol=PROJ_ATOL * np.abs(want).max())
 
 
 def test_two_column_passes_at_production_size_against_the_oracle():
@@ -794,7 +803,7 @@ def test_two_column_passes_at_production_size_against_the_oracle():
     ratio = (sing[:k].astype(np.float64) ** 2) / (sing[:k].astype(np.float64) ** 2).sum()
     np.testing.assert_allclose(pca.explained_variance_ratio(np.float64), ratio, atol=1e-6)
     want = orc.transform_sparse(ptr, idx, val, m, n, comps, mean, True)
-    np.testing.assert_allclose(t, want, atol=2e-3 * np.abs(want).max())
+    np.testing.assert_allclose(t, want, atol=PROJ_ATOL * np.abs(want).max())
 
 
 def test_masked_randomized_on_the_bucket_route_at_production_size_against_the_oracle():
@@ -825,7 +834,7 @@ def test_masked_randomized_on_the_bucket_route_at_production_size_against_the_or
     mean_full = np.bincount(idx, weights=val, minlength=n) / m               # every column, masked-out ones included
     np.testing.assert_allclose(est.mean_(np.float64), mean_full, rtol=2e-6, atol=1e-8)
     want = orc.transform_masked(ptr, idx, val, m, comps[:k], mean_full, True, o2m)
-    np.testing.assert_allclose(t, want, atol=2e-3 * np.abs(want).max())
+    np.testing.assert_allclose(t, want, atol=PROJ_ATOL * np.abs(want).max())
 
 
 def test_properties_at_the_c3_size():
@@ -911,7 +920,7 @@ def test_g6_lanczos_masked(golden):
 
 
 @pytest.mark.parametrize("dtype,masked", [(np.float64, True), (np.float64, False), (np.float32, True)])
-def test_lanczos_without_a_transposed_operator(monkeypatch, dtype, masked):
+def test_lanczos_without_a_transposed_operator(debug_switches, monkeypatch, dtype, masked):
     """Lanczos fits whose transposed side fits LDS build no A^T: the second product of a step scatters A's rows into
     per-workgroup FIXED-POINT copies of the output (scatter.hip), the column statistics come from the same kind of pass.
     (1) bit-for-bit reproducible (integer sums: no order dependence); (2) the same fit as the transposed route
@@ -1265,7 +1274,7 @@ def test_fit_after_the_uploaded_values_were_edited_in_place():
     assert O.subspace_angle(pca.components_(np.float64), want.components) < 1e-4
 
 
-def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
+def test_every_route_to_the_transposed_format_gives_the_same_fit(debug_switches, monkeypatch):
     """A^T's tile-major format can come from the tile-major transposed rows still packed by the sort (default),
     from the same rows unpacked into a CSR, from a naturally ordered transposed CSR, or straight from A: the
     bytes are the same, hence bit-identical fits"""
@@ -1300,7 +1309,7 @@ def test_every_route_to_the_transposed_format_gives_the_same_fit(monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(30000, 2500), (700, 5000), (2500, 70), (100000, 300), (3000, 70000)])
-def test_bucket_route_to_the_transposed_format_on_skewed_columns(monkeypatch, shape):
+def test_bucket_route_to_the_transposed_format_on_skewed_columns(debug_switches, monkeypatch, shape):
     """A^T's format straight from A (per-chunk buckets) against the transposition route on matrices whose columns differ
     in density by two orders of magnitude (A^T's rows get sorted by length: blocks cut by entry count, rows permuted),
     tall, wide and narrow, and with more columns than the bucket route takes (65536: the transposition steps in while the
@@ -1340,7 +1349,7 @@ def test_bucket_route_to_the_transposed_format_on_skewed_columns(monkeypatch, sh
 
 @pytest.mark.parametrize("case", [(6000, 1500, 0.05), (40000, 3000, 0.02), (3000, 20000, 0.01), (4000, 2000, 0.5), (2500, 70, 0.2),
                                   (1000, 40000, 0.004)])
-def test_gather_fill_and_bucket_route_write_the_same_format(monkeypatch, case):
+def test_gather_fill_and_bucket_route_write_the_same_format(debug_switches, monkeypatch, case):
     """A^T's format in natural row order: every chunk gathers its runs of A's rows itself (default; the run ends come from
     the histogram pass) or reads the bucket a scatter pass filled (SAPCA_AT_BUCKETS=1) -- the same bytes and the same
     per-tile column sums, hence bit-identical fits.  Blocks of 512 and of 1024 rows, chunks above the ten entries a thread
@@ -1375,7 +1384,7 @@ def test_gather_fill_and_bucket_route_write_the_same_format(monkeypatch, case):
     np.testing.assert_allclose(out[0][1], want.mean, atol=1e-6)
 
 
-def test_bucket_route_on_a_half_dense_matrix(monkeypatch):
+def test_bucket_route_on_a_half_dense_matrix(debug_switches, monkeypatch):
     """chunks of 80 000 entries (512 columns x 320 rows at density 0.5): the fill keeps ten entries per thread in registers
     and takes the rest of its bucket from memory; (row, tile) segments of up to 320 entries.  Against the transposition
     route and the oracle."""
@@ -1400,7 +1409,7 @@ def test_bucket_route_on_a_half_dense_matrix(monkeypatch):
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=2e-4)
 
 
-def test_tile_major_builder_with_and_without_its_lds_table(monkeypatch):
+def test_tile_major_builder_with_and_without_its_lds_table(debug_switches, monkeypatch):
     """A^T's format: the row-segment bounds staged in LDS (few tiles) or read from global memory one tile ahead
     (many tiles, C4/C5) -- the same bytes, hence bit-identical fits"""
     m, n, k, p, q = 9000, 700, 8, 6, 2
@@ -1418,7 +1427,7 @@ def test_tile_major_builder_with_and_without_its_lds_table(monkeypatch):
     np.testing.assert_allclose(out[0][0], want.singular_values, rtol=1e-4)
 
 
-def test_staged_and_direct_format_fill_agree(monkeypatch):
+def test_staged_and_direct_format_fill_agree(debug_switches, monkeypatch):
     """the LDS-staged builder of A's tile-major format and the direct one write the same bytes: bit-identical
     fits; a matrix with a few very long rows sends some quads down the direct route inside the staged kernel"""
     m, n, k, p, q = 5000, 3000, 10, 6, 2
@@ -1555,7 +1564,7 @@ def test_resident_workflow_normalize_log1p_pca():
     assert t.shape == (m, k)
 
 
-def test_rows_sorted_by_length_on_a_skewed_matrix(monkeypatch):
+def test_rows_sorted_by_length_on_a_skewed_matrix(debug_switches, monkeypatch):
     """log-normal row lengths and power-law column popularity (cell depth, gene detection rate): the staged formats
     sort rows by length and cut blocks by entry count; forced on and off, against the oracle"""
     m, n, k, p, q = 5000, 800, 8, 6, 2
@@ -1717,7 +1726,7 @@ def test_projection_through_an_operator_whose_tile_range_is_split(semantics):
 
 
 @pytest.mark.parametrize("l", [1, 2, 3, 7, 16, 33, 60, 61, 90, 111, 112, 113])
-def test_device_eigensolver_against_the_host_one(monkeypatch, l):
+def test_device_eigensolver_against_the_host_one(debug_switches, monkeypatch, l):
     """the l x l Gram of the small SVD: parallel Jacobi in one workgroup on the device (l <= 112, SAPCA_EIG_DEVICE=1: an
     experiment, four times slower than the default) against the host's Householder + QL (l = 113 takes the host on both runs) -- the same singular values to 1e-6 relative
     (f32 panels upstream: both solvers see the same f64 Gram, and agree to ~1e-12 of sigma_0), the same subspace, the same
@@ -1746,7 +1755,7 @@ def test_device_eigensolver_against_the_host_one(monkeypatch, l):
     np.testing.assert_allclose(np.abs(out[0][2][:, :j]), np.abs(out[1][2][:, :j]), atol=2e-3 * np.abs(out[1][2]).max())
 
 
-def test_device_eigensolver_on_a_rank_deficient_gram(monkeypatch):
+def test_device_eigensolver_on_a_rank_deficient_gram(debug_switches, monkeypatch):
     """more panel columns than the matrix has rank: the Gram has zero eigenvalues; the solver must converge (rotations against
     rounding noise are skipped) and the surplus directions come out as zero components with sigma ~ 0"""
     rng = np.random.default_rng(5)
@@ -1767,7 +1776,7 @@ def test_device_eigensolver_on_a_rank_deficient_gram(monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SAPCA_FUZZ_SEEDS", "20"))))   # (SAPCA_FUZZ_SEEDS=300: a longer soak)
-def test_gather_fill_on_random_shapes_is_the_bucket_route_bit_for_bit(monkeypatch, seed):
+def test_gather_fill_on_random_shapes_is_the_bucket_route_bit_for_bit(debug_switches, monkeypatch, seed):
     """random shapes (1 to 500 tiles of A rows, 70 to 60 000 columns: block counts from a few to 64, blocks of 512 and of 1024
     rows), densities from 0.2 % to 30 %, a few dense rows and empty rows thrown in: A^T's format through the gather fill and
     through the bucket route must give bit-identical fits (same bytes, same per-tile column sums)"""
