@@ -1002,7 +1002,14 @@ void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
   h.small_pending = false;
   // fit_transform of an unmasked f32 randomized fit: the small SVD's host half is held back until transform() has queued
   // the projection sweep (masked fits finish first, see below)
-  h.defer_small = defer_finish && h.mask.empty() && h.opt.method == SAPCA_RANDOM && sizeof(T) == 4;
+  // ... where that pays: the rotation is one more m x l by l x k panel product (0.2 ms per million rows at l <= 64, four
+  // times that at 128 columns) against a host stall of 0.25 ms (l = 60) to 1 ms (l = 110) -- C2 and the shards of a
+  // strong-scaled fit gain 0.2 ms of a 9.5 ms step, a million rows on one GPU would lose as much (measured, round 4).
+  {
+    const double lw = (double)(h.opt.n_components + h.opt.n_oversamples) <= 64 ? 64.0 : 128.0;
+    h.defer_small = defer_finish && h.mask.empty() && h.opt.method == SAPCA_RANDOM && sizeof(T) == 4 &&
+                    (double)A.rows * lw * lw <= 400e3 * 64.0 * 64.0;
+  }
   h.spans.clear();
   h.comm.host_ms = 0;
   h.timer.begin_collect(s, h.opt.collect_timings != 0);

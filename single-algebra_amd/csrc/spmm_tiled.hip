@@ -596,21 +596,20 @@ quad_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ id
 // (very long rows) take the direct route and zero their padding themselves, so the entry buffer
 // needs no memset on this path.
 constexpr int QF_CAP_MIN = 4096, QF_CAP_MAX = 6144;   // entries of one quad staged in LDS: 32 KiB (more workgroups per CU) .. 48 KiB
+// (quad `qi` of the operator: rb = qi / Q_BLOCK_QUADS, qd = qi % Q_BLOCK_QUADS; all 256 threads of the workgroup)
 template <typename VT>
-__global__ void __launch_bounds__(256)
-quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const VT* __restrict__ val,
-                        const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
-                        const uint32_t* __restrict__ perm, int nct, int cap, float inv_nct,
-                        int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
-                        typename EntOf<VT>::type* __restrict__ ent) {
+__device__ __forceinline__ void quad_fill_staged_one(int qi, uint32_t* qf_lds, const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                     const VT* __restrict__ val, const int32_t* __restrict__ seg,
+                                                     const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct, int cap,
+                                                     float inv_nct, int ldp_bytes, const int64_t* __restrict__ chunk_off,
+                                                     const uint32_t* __restrict__ quad_off, typename EntOf<VT>::type* __restrict__ ent) {
   typedef typename EntOf<VT>::type E;
   constexpr int EW = (int)sizeof(E) / 4;   // entry size in LDS words
-  extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
   E* stage = reinterpret_cast<E*>(qf_lds);         // [cap]
   int64_t* gofs = reinterpret_cast<int64_t*>(qf_lds + EW * cap);   // [nct] where the quad's segment of tile t goes
   uint32_t* lofs = qf_lds + EW * cap + 2 * nct;     // [nct + 1] start of every tile's segment in the image
   uint32_t* cnt_all = lofs + nct + 1;              // [4][nct] entries of row g seen so far in tile t
-  const int rb = blockIdx.x / Q_BLOCK_QUADS, qd = blockIdx.x % Q_BLOCK_QUADS;
+  const int rb = qi / Q_BLOCK_QUADS, qd = qi % Q_BLOCK_QUADS;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   if (4 * qd >= nrows) return;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
@@ -711,6 +710,21 @@ quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restri
     const uint32_t lo = lofs[t], n = lofs[t + 1] - lo;
     E* dst = ent + gofs[t];
     for (uint32_t j = lane; j < n; j += WAVE) dst[j] = stage[lo + j];
+  }
+}
+
+// A workgroup walks quads qi = blockIdx.x, blockIdx.x + gridDim.x, ... (the default grid is one workgroup per quad: qf_grid).
+template <typename VT>
+__global__ void __launch_bounds__(256)
+quad_fill_staged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const VT* __restrict__ val,
+                        const int32_t* __restrict__ seg, const int32_t* __restrict__ blk_row0,
+                        const uint32_t* __restrict__ perm, int nct, int cap, float inv_nct,
+                        int ldp_bytes, const int64_t* __restrict__ chunk_off, const uint32_t* __restrict__ quad_off,
+                        typename EntOf<VT>::type* __restrict__ ent, int nquads_all) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t qf_lds[];
+  for (int qi = blockIdx.x; qi < nquads_all; qi += gridDim.x) {
+    quad_fill_staged_one<VT>(qi, qf_lds, ptr, idx, val, seg, blk_row0, perm, nct, cap, inv_nct, ldp_bytes, chunk_off, quad_off, ent);
+    __syncthreads();   // (the image and its tables are reused by the next quad)
   }
 }
 
@@ -1983,6 +1997,19 @@ void natural_partition(int64_t op_rows, int nct, int block_rows, int64_t& nrb, i
   }
 }
 
+// workgroups of the staged fill: one per quad.  (The kernel can walk several quads per workgroup -- -DSAPCA_QF_WGS=n caps the
+// grid: measured at C2 / C4 with 1024, 2048, 4096 workgroups, round 4: the same 2.0 ms preparation at C2 and +0.8 ms at C4
+// (gpurun_out/r4_ab_qf.txt, r4_ab_c4.txt) -- the fill runs beside A^T's builder, which holds every wave slot of a CU while
+// its workgroups are resident, so what this kernel gets are the gaps, and short-lived workgroups fill gaps best.)
+inline unsigned qf_grid(int64_t nquads) {
+#ifdef SAPCA_QF_WGS
+  const int64_t wgs = SAPCA_QF_WGS;
+#else
+  const int64_t wgs = nquads;
+#endif
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nquads, wgs));
+}
+
 template <typename VT>
 bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp& op, TiledBuffers& buf, hipStream_t s,
                    bool rows_tile_major, const uint64_t* packed_rows, bool allow_big_tile, bool seg_ready,
@@ -2298,9 +2325,9 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       hipLaunchKernelGGL(quad_fill_runs_kernel<false>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), 0, s, S.ptr, S.idx, S.val,
                          packed_rows, d_seg, d_blk, d_perm, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
   } else if (staged_fill)
-    hipLaunchKernelGGL(quad_fill_staged_kernel<float>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256),
+    hipLaunchKernelGGL(quad_fill_staged_kernel<float>, dim3(qf_grid((int64_t)nrb * Q_BLOCK_QUADS)), dim3(256),
                        (size_t)qf_cap * sizeof(Ent) + ((size_t)7 * nct + 1) * sizeof(uint32_t), s, S.ptr, S.idx, S.val, d_seg, d_blk,
-                       d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+                       d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent, (int)(nrb * Q_BLOCK_QUADS));
   else if (quad)
     hipLaunchKernelGGL(quad_fill_kernel<float>, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
@@ -2326,8 +2353,8 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       const size_t fill_lds = (size_t)qf_cap * sizeof(E) + ((size_t)7 * nct + 1) * sizeof(uint32_t);
       static LdsAttrState attr;
       ensure_dynamic_lds(reinterpret_cast<const void*>(&quad_fill_staged_kernel<double>), fill_lds, attr);
-      hipLaunchKernelGGL(quad_fill_staged_kernel<double>, dim3((unsigned)(nrb * Q_BLOCK_QUADS)), dim3(256), fill_lds, s, S.ptr, S.idx,
-                         S.val, d_seg, d_blk, d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);
+      hipLaunchKernelGGL(quad_fill_staged_kernel<double>, dim3(qf_grid((int64_t)nrb * Q_BLOCK_QUADS)), dim3(256), fill_lds, s, S.ptr, S.idx,
+                         S.val, d_seg, d_blk, d_perm, nct, qf_cap, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent, (int)(nrb * Q_BLOCK_QUADS));
     } else
     hipLaunchKernelGGL(quad_fill_kernel<double>, dim3((unsigned)((S.rows + 3) / 4)), dim3(256), (size_t)4 * nct * sizeof(uint32_t), s,
                        S.ptr, S.idx, S.val, S.rows, d_blk, d_perm, (int)nrb, nct, inv_nct, ldp * 4, d_chunk, d_quad_off, d_ent);

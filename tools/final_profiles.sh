@@ -10,5 +10,5 @@ for wl in c3 c4 c5; do
 done
 ( timeout -k 10 200 python3 tools/masked_random_time.py; timeout -k 10 200 python3 tools/masked_random_time.py f64 ) > $out/${tag}_masked_randomized_c3_matrix.txt 2>/dev/null
 timeout -k 10 200 python3 tools/shape_time.py 200000 20000 0.03 50 10 4 3 f64 > $out/${tag}_c2_matrix_f64.txt 2>/dev/null
-( echo "== statistics behind the upload (default)"; timeout -k 10 200 python3 tools/host_path_time.py; echo "== SAPCA_UPLOAD_STATS_OFF=1"; SAPCA_UPLOAD_STATS_OFF=1 timeout -k 10 200 python3 tools/host_path_time.py ) > $out/${tag}_host_path.txt 2>/dev/null
+( echo "== statistics behind the upload (default)"; timeout -k 10 200 python3 tools/host_path_time.py; echo "== SAPCA_UPLOAD_STATS_OFF=1 (a switch of the debug variant: csrc/switches.h)"; SAPCA_LIB_PATH=$GRAFT_REPO_ROOT/single-algebra_amd/lib/libsapca_dbg.so SAPCA_UPLOAD_STATS_OFF=1 timeout -k 10 200 python3 tools/host_path_time.py ) > $out/${tag}_host_path.txt 2>/dev/null
 ls -la $out

@@ -13,9 +13,9 @@ for r in csv.DictReader(open(tr[0])): dur[r["Dispatch_Id"]]=(int(r["End_Timestam
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter(); dsum=collections.defaultdict(float); seen=set()
 for r in csv.DictReader(open(f[0])):
     k=r["Kernel_Name"]
-    if not any(s in k for s in ("gram_kernel","panel_gemm","chol_inv")): continue
+    if not any(s in k for s in ("gram_kernel","gramv_kernel","gram_split_kernel","panel_gemm","chol_inv")): continue
     import re
-    k=re.search(r"(gram_kernel|panel_gemm_kernel|chol_inv\w*)(<[^>]*>)?", k).group(0)
+    k=re.search(r"(gramv_kernel|gram_split_kernel|gram_kernel|panel_gemm_kernel|chol_inv\w*)(<[^>]*>)?", k).group(0)
     acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
     if (k,r["Dispatch_Id"]) not in seen:
         seen.add((k,r["Dispatch_Id"])); dsum[k]+=dur.get(r["Dispatch_Id"],0)
