@@ -41,7 +41,7 @@ WORKLOADS = {
     # BASELINE.json configs[2]: MaskedSparsePCA, f64, 60 % feature mask, SVDMethod::Lanczos k=30 (p, q unused)
     "c3": (200_000, 30_000, 0.03, 30, 0, 0),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy; the line carries this box's own: peak_measured)
 
 
 def alg_bytes(m, n, nnz, l, k, q, tsize=4):

@@ -129,16 +129,20 @@ void normalize_csr(const CsrView<T>& A, T* values, const double* d_sums, double 
 
 // A 16-byte-per-lane streaming copy: what this device's HBM delivers to a kernel of this library (read + write), the
 // attainable figure bench.py reports beside the 8 TB/s of the data sheet.
-__global__ void __launch_bounds__(256) copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+typedef unsigned int copy_u4 __attribute__((ext_vector_type(4)));
+// (one 16-byte element per thread, one short workgroup per 4 KiB: of the launch shapes tried in tools/ubench/copy_bw.hip this is
+//  the one that reaches the guide's figure -- 6.25 TB/s; grid-stride loops over 2048..16384 workgroups gave 4.5-5.2, hipMemcpy 5.2)
+__global__ void __launch_bounds__(256) copy16_kernel(const copy_u4* __restrict__ src, copy_u4* __restrict__ dst, int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 
 void stream_copy16(const void* src, void* dst, int64_t bytes, hipStream_t s) {
   const int64_t n16 = bytes / 16;
   if (n16 == 0) return;
-  // (8 workgroups of 256 threads per CU: every lane keeps a few 16-byte loads in flight)
-  hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, s, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+  SAPCA_CHECK((n16 + 255) / 256 < ((int64_t)1 << 31), SAPCA_ERR_ARG, "stream_copy16: more than 2^31 workgroups");
+  hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, static_cast<const copy_u4*>(src),
+                     static_cast<copy_u4*>(dst), n16);
   SAPCA_HIP(hipGetLastError());
 }
 

@@ -3,12 +3,12 @@
 # sweep kernels' counters and durations (the effective clock of a dispatch is GRBM_GUI_ACTIVE / 8 / duration)
 cd /tmp; export TMPDIR=/tmp
 tag=$1; shift
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.err
+rm -rf /tmp/pmc_$tag
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pmc_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> /tmp/pmc_$tag.err
 python3 - <<PY
 import csv,glob,collections
-f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/*/*counter_collection.csv")
-kt=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/*/*kernel_trace.csv")
+f=glob.glob("/tmp/pmc_$tag/*/*counter_collection.csv")
+kt=glob.glob("/tmp/pmc_$tag/*/*kernel_trace.csv")
 if not f: print("no counter file"); raise SystemExit
 dur={}
 if kt:

@@ -2,12 +2,12 @@
 # MFMA / VALU counters of the dense kernels (Gram, panel GEMM, Cholesky) over one bench step: tools/pmc_mfma.sh <tag> <workload>
 cd /tmp; export TMPDIR=/tmp
 tag=$1; wl=${2:-c2}
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> /tmp/pmc_$tag.err
 python3 - <<PY
 import csv,glob,collections
-f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/*/*counter_collection.csv")
+f=glob.glob("/tmp/pmc_$tag/*/*counter_collection.csv")
 if not f: print("no counter file"); raise SystemExit
-tr=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/*/*kernel_trace.csv")
+tr=glob.glob("/tmp/pmc_$tag/*/*kernel_trace.csv")
 dur={}
 for r in csv.DictReader(open(tr[0])): dur[r["Dispatch_Id"]]=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter(); dsum=collections.defaultdict(float); seen=set()
