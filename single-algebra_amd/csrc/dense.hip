@@ -1188,17 +1188,24 @@ flip_sign_partial_kernel(const T* __restrict__ VtT, int64_t n, int ld, int64_t r
 }
 
 template <typename T>
-__global__ void flip_sign_final_kernel(const T* __restrict__ VtT, int64_t n, int ld, int k, int nblocks, const double* __restrict__ part_a,
-                                       const long long* __restrict__ part_i, double* __restrict__ sign) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= k) return;
+__global__ void __launch_bounds__(64)
+flip_sign_final_kernel(const T* __restrict__ VtT, int64_t n, int ld, int k, int nblocks, const double* __restrict__ part_a,
+                       const long long* __restrict__ part_i, double* __restrict__ sign) {
+  const int c = blockIdx.x;   // a wave per column
   double ba = -1.0;
   long long bi = 0x7fffffffffffffffLL;
-  for (int b = 0; b < nblocks; ++b) {   // (blocks hold ascending row ranges: a strict > keeps the first row on ties)
+  for (int b = threadIdx.x; b < nblocks; b += WAVE) {
     const double oa = part_a[(int64_t)b * ld + c];
-    if (oa > ba) { ba = oa; bi = part_i[(int64_t)b * ld + c]; }
+    const long long oi = part_i[(int64_t)b * ld + c];
+    if (oa > ba || (oa == ba && oi < bi)) { ba = oa; bi = oi; }
   }
-  sign[c] = (n > 0 && ba >= 0.0 && (double)VtT[bi * ld + c] < 0) ? -1.0 : 1.0;
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) {
+    const double oa = __shfl_xor(ba, off);
+    const long long oi = __shfl_xor(bi, off);
+    if (oa > ba || (oa == ba && oi < bi)) { ba = oa; bi = oi; }   // (larger |v|; the first row on ties)
+  }
+  if (threadIdx.x == 0) sign[c] = (n > 0 && ba >= 0.0 && (double)VtT[bi * ld + c] < 0) ? -1.0 : 1.0;
 }
 
 template <typename T>
@@ -1636,7 +1643,7 @@ void flip_transpose(const T* VtT, int64_t n, int ld, int k, T* components, DevBu
     long long* part_i = reinterpret_cast<long long*>(part_a + (size_t)nblocks * ld);
     if (sign_out) *sign_out = sign;
     hipLaunchKernelGGL((flip_sign_partial_kernel<T>), dim3(nblocks), dim3(256), 0, s, VtT, n, ld, rpb, part_a, part_i);
-    hipLaunchKernelGGL((flip_sign_final_kernel<T>), dim3((k + 63) / 64), dim3(64), 0, s, VtT, n, ld, k, nblocks, part_a, part_i, sign);
+    hipLaunchKernelGGL((flip_sign_final_kernel<T>), dim3(k), dim3(64), 0, s, VtT, n, ld, k, nblocks, part_a, part_i, sign);
     hipLaunchKernelGGL((flip_transpose_kernel<T>), dim3(grid_for((int64_t)k * n, 256)), dim3(256), 0, s, VtT, n, ld, k,
                        sign, components);
     SAPCA_HIP(hipGetLastError());
