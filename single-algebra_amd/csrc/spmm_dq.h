@@ -5,12 +5,15 @@
 namespace sapca {
 namespace k {
 
-// Steps of a quad in a tile = its longest row segment, rounded up to an even count unless the build lets quads end on any
-// step (-DSAPCA_ODD_STEPS: the DPP-fed sweep's main loop is then generated with DQ2_ODD=1 and counts per step).
-#ifdef SAPCA_ODD_STEPS
-constexpr bool kOddSteps = true;
-#else
+// Steps of a quad in a tile = its longest row segment: a quad may end on any step (round 4; the generated main loop counts
+// per step, tools/gen_spmm_dq2.py DQ2_ODD=1).  -DSAPCA_EVEN_STEPS brings back the format of rounds 2-3, which rounded a quad's
+// steps up to an even count (3.8 % more executed slots at C2, 10 % more at C5's 3.2 entries per row and tile) for a counter
+// per two-step group; the main loop must then be generated with DQ2_ODD=0.  Measured same-box (profiles/r04_ab_odd_*.txt):
+// C2 sweep -1.4 %, C5 sweep -3.4 % and preparation -5 %, C4 -0.1 %.
+#ifdef SAPCA_EVEN_STEPS
 constexpr bool kOddSteps = false;
+#else
+constexpr bool kOddSteps = true;
 #endif
 
 // Per (row block, wave, tile) stream offsets / chunk counts and the per-two-step row-slot descriptors of a built

@@ -3,7 +3,7 @@
 # CXXDEFS, in compile-time switches of spmm_dq.hip / spmm_tiled.hip):
 #   tools/dq2_variant.sh NAME [ENV=VALUE ...]   ->  single-algebra_amd/lib/exp/libsapca_NAME.so
 # The switches are those of tools/gen_spmm_dq2.py (DQ2_B64=1, DQ2_FMAC=1, DQ2_DEPTH=3, DQ2_PRIO=1, DQ2_ODD=1);
-# CXXDEFS="-DSAPCA_ODD_STEPS" goes to the compiler (DQ2_ODD=1 needs it: format and main loop must agree).  Run one with
+# CXXDEFS="-DSAPCA_EVEN_STEPS" goes to the compiler (DQ2_ODD=0 needs it: format and main loop must agree).  Run one with
 # SAPCA_LIB_PATH=single-algebra_amd/lib/exp/libsapca_NAME.so python3 tools/abl_run.py
 set -e
 cd "$(dirname "$0")/../single-algebra_amd"

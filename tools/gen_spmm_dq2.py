@@ -46,7 +46,7 @@ VA64 = 30         # v[30:31]: 64-bit source address of an LDS-DMA piece
 W = [[32, 36], [40, 44]]
 VCNT, VCNT2 = 48, 49   # two-step groups - 1 of this wave's quads in the current tile (lane j = quad j; -1: none); raw step counts of the next
 DEPTH = int(os.environ.get("DQ2_DEPTH", "2"))   # two-step groups in flight per wave (3: a third register set behind the accumulators)
-ODD = os.environ.get("DQ2_ODD", "0") != "0"     # quads of any step count (the format no longer rounds a quad's steps up to even): the counter runs per step
+ODD = os.environ.get("DQ2_ODD", "1") != "0"     # quads of any step count (the format does not round a quad's steps up to even: the default since round 4): the counter runs per step; DQ2_ODD=0 + -DSAPCA_EVEN_STEPS: rounds 2-3
 PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from the info table
 ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved with the next group's DPP instructions, reads last
 # experiment switches (environment, read when the header is generated)
