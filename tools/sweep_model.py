@@ -68,13 +68,18 @@ def steps_of(cnt, lock, even=True, sort_rows=False):
     return st
 
 
-def analyse(cnt, lock, quads_per_wave, *, even=True, sort_rows=False):
+def analyse(cnt, lock, quads_per_wave, *, even=True, sort_rows=False, deal=False):
     st = steps_of(cnt, lock, even, sort_rows)                # [quads, tiles]
     nq, nct = st.shape
-    padq = (-nq) % quads_per_wave
-    if padq:
-        st = np.vstack([st, np.zeros((padq, nct), st.dtype)])
-    wave = st.reshape(-1, quads_per_wave, nct).sum(1)        # steps of every wave in every tile
+    # the kernel's split of a block's quads over its 16 waves: wave w walks quads [w nq / 16, (w + 1) nq / 16) (q_first() in
+    # spmm_tiled.hip) -- every wave the same count to within one, whatever the block's row count; `deal`: wave w walks quads
+    # w, w + 16, ... instead (same counts, every wave a sample of the whole block)
+    nw = 16 * 16 // quads_per_wave if quads_per_wave != 16 else 16
+    nw = 16
+    wave = np.zeros((nw, nct), dtype=np.int64)
+    for w in range(nw):
+        sel = np.arange(w, nq, nw) if deal else np.arange(w * nq // nw, (w + 1) * nq // nw)
+        wave[w] = st[sel].sum(0)
     slots = int(st.sum()) * lock
     barrier = wave.max(0).sum()                              # a barrier per tile: the slowest wave sets the pace
     mean = wave.sum(1).mean()
@@ -134,6 +139,7 @@ def main():
         # name, lockstep rows, quads per wave, VALU+LDS cycles per step per SIMD (issue floor), kwargs
         ("current: 4-row lockstep, even steps", 4, 16, 2 * 4.6 + 2 * 5.2, {}),
         ("4-row lockstep, odd steps allowed", 4, 16, 2 * 4.6 + 2 * 5.2, {"even": False}),
+        ("odd steps + quads dealt to the waves round-robin", 4, 16, 2 * 4.6 + 2 * 5.2, {"even": False, "deal": True}),
         ("4-row lockstep, rows sorted by length in the block", 4, 16, 2 * 4.6 + 2 * 5.2, {"sort_rows": True}),
         ("2-row lockstep (32 lanes x 2 columns)", 2, 32, 2 * 4.6 + 1 * 5.2, {}),
         ("1 row per wave-step (64 lanes x 1 column, scalar-fed)", 1, 64, 4.0 + 4.0, {"even": False}),
