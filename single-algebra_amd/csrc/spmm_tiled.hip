@@ -2394,8 +2394,15 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   int64_t* bnd = nullptr;
   if (dbg_env("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096) {
     const size_t bytes = (size_t)(nrb_nat + 1) * (size_t)nct * tc * sizeof(int64_t);
-    bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
-    SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
+    // (8 (nrb + 1) bytes per row of A: 264 MB at C4, gigabytes at 10M rows -- a table that cannot be allocated is not a failed
+    //  fit: the bucket route needs none)
+    try {
+      bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
+    } catch (const Error&) {
+      (void)hipGetLastError();
+      bnd = nullptr;
+    }
+    if (bnd) SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
   }
   const size_t hist_lds = (size_t)n2 * 2;
   static LdsAttrState hist_attr;
