@@ -1191,12 +1191,12 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       }
     }
     const T* mu = h.mean_used_dev.ptr<T>();
-    if (h.small_pending && prepared && !masked) {
-      // fit_transform, f32 randomized: the fit stopped in front of the host eigensolver.  The projection is linear in the
-      // components: with vt^T = B^T M (M = Uh S^-1 diag(sign), l x k) the reference's t = Ac diag(cnt) vt^T (Q2; cnt = 1 for the
-      // centred semantics) is [Ac diag(cnt) B^T] M -- the sweep runs on the un-rotated n x l panel while the host solves the
-      // l x l eigenproblem, and one m x l by l x k panel product rotates its result.  (B^T = panel_x; Q = panel_y is free.)
-      const int l = h.small_l, ld = h.small_ld;
+    // fit_transform, f32 randomized: the fit stopped in front of the host eigensolver.  The projection is linear in the
+    // components: with vt^T = B^T M (M = Uh S^-1 diag(sign), l x k) the reference's t = Ac diag(cnt) vt^T (Q2; cnt = 1 for the
+    // centred semantics) is [Ac diag(cnt) B^T] M -- the sweep runs on the un-rotated n x l panel while the host solves the
+    // l x l eigenproblem, and one m x l by l x k panel product rotates its result.  (B^T = panel_x; Q = panel_y is free.)
+    auto project_unrotated = [&] {
+      const int ld = h.small_ld;
       const SmallLayout lay(ld);
       double* small = h.small.as<double>(lay.doubles());
       T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
@@ -1208,50 +1208,53 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       k::scale_rows(X, n_used, ld, ref_sem ? d_cnt : nullptr, Xs, s);
       if (center) k::weighted_colsum(Xs, n_used, ld, mu, cvec, h.scratch2, s);
       k::spmm(Au, topl, Xs, ld, Tp, ld, ld, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
-      (void)l;
       const double* sign = nullptr;
       finish_small_svd(h, &sign);   // (waits for the Gram's copy only; the sweep above is running)
       const int ldm = (int)round_up(k, 16);
       k::scale_columns(Mdev, ld, ldm, k, sign, s);
       k::panel_gemm(Tp, m, ld, Mdev, ldm, d_out, s, false, k, k);
-      goto projected;
-    }
-    if (h.small_pending) finish_small_svd(h, nullptr);
-    {
-    const SmallLayout lay(ldk);
-    double* small = h.small.as<double>(lay.doubles());
-    T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
-    const T* comps = h.components_dev.ptr<T>();
-    T* W = h.panel_w.as<T>((size_t)n_used * ldk);
-    if (ref_sem && !masked) {
-      // Q2 (sparse/mod.rs:268-282): t_ik = sum_j cnt_j (x_ij - [center] mu_j) V_kj
-      k::scaled_transpose(comps, n_used, k, d_cnt, W, ldk, s);
-      if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
-      k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
-    } else if (ref_sem && masked) {
-      // Q3 (sparse_masked/mod.rs:488-529): mean subtracted at stored, kept entries only
-      k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
-      bool done = false;
-      if constexpr (sizeof(T) == 4) {
-        // the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (spmm_dq.hip)
-        if (center && top && h.opt.spmm_variant != 1 && !h.q3_cancels && dbg_env("SAPCA_Q3_ROWKERNEL") == nullptr) {
-          float* W2 = h.scratch2.as<float>((size_t)n_used * ldk);
-          float* tmp = h.panel_y.as<float>((size_t)m * std::max(k, 1));
-          done = k::q3_projection_dq(Au, *top, W, ldk, mu, W2, tmp, d_out, k, s);
+    };
+    // the projection with the fitted components (a separate transform, masked fits, f64, Lanczos, large m)
+    auto project_with_components = [&] {
+      const SmallLayout lay(ldk);
+      double* small = h.small.as<double>(lay.doubles());
+      T* cvec = reinterpret_cast<T*>(small + lay.cvec_at());
+      const T* comps = h.components_dev.ptr<T>();
+      T* W = h.panel_w.as<T>((size_t)n_used * ldk);
+      if (ref_sem && !masked) {
+        // Q2 (sparse/mod.rs:268-282): t_ik = sum_j cnt_j (x_ij - [center] mu_j) V_kj
+        k::scaled_transpose(comps, n_used, k, d_cnt, W, ldk, s);
+        if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
+        k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
+      } else if (ref_sem && masked) {
+        // Q3 (sparse_masked/mod.rs:488-529): mean subtracted at stored, kept entries only
+        k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+          // the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (spmm_dq.hip)
+          if (center && top && h.opt.spmm_variant != 1 && !h.q3_cancels && dbg_env("SAPCA_Q3_ROWKERNEL") == nullptr) {
+            float* W2 = h.scratch2.as<float>((size_t)n_used * ldk);
+            float* tmp = h.panel_y.as<float>((size_t)m * std::max(k, 1));
+            done = k::q3_projection_dq(Au, *top, W, ldk, mu, W2, tmp, d_out, k, s);
+          }
         }
+        if (!done) {
+          if (center) k::spmm_rows_shifted(Au, W, ldk, d_out, k, k, mu, s);   // (the row kernel subtracts mu_j entry by entry)
+          else k::spmm(Au, top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
+        }
+      } else {
+        // opt-in: the mathematically centred projection (A - 1 mu^T) V^T
+        k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
+        if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
+        k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
       }
-      if (!done) {
-        if (center) k::spmm_rows_shifted(Au, W, ldk, d_out, k, k, mu, s);   // (the row kernel subtracts mu_j entry by entry)
-        else k::spmm(Au, top, W, ldk, d_out, k, k, (const T*)nullptr, h.opt.spmm_variant, h.split_scratch, s);
-      }
+    };
+    if (h.small_pending && prepared && !masked) {
+      project_unrotated();
     } else {
-      // opt-in: the mathematically centred projection (A - 1 mu^T) V^T
-      k::scaled_transpose(comps, n_used, k, (const double*)nullptr, W, ldk, s);
-      if (center) k::weighted_colsum(W, n_used, ldk, mu, cvec, h.scratch2, s);
-      k::spmm(Au, top, W, ldk, d_out, k, k, center ? cvec : nullptr, h.opt.spmm_variant, h.split_scratch, s);
+      if (h.small_pending) finish_small_svd(h, nullptr);   // (a held-back small SVD whose projection cannot take the un-rotated route)
+      project_with_components();
     }
-    }
-  projected:;
   }
   SAPCA_HIP(hipStreamSynchronize(s));
   finish_fit(h);   // (fit_transform: the fit's host-side tail, held back until the projection was queued)
