@@ -35,6 +35,26 @@ struct SmallLayout {
   size_t wsum_at() const { return 6 * W * W + 64 + 2 * W; }   // W doubles behind c | s: the column sums a Gram pass gathers
 };
 
+
+// Does the LDS-staged sweep pay on an operator of `rows` x `cols` with `entries` stored entries and panels of l columns?  It
+// refills an 80 KiB panel tile per (row block, column tile) chunk and only beats the row-gather kernel when a chunk carries
+// enough entries to amortise that fill (measured: 64 tile bytes per entry or less -> clearly faster; 164 -> no gain, 4x the
+// preparation), and small operators stay on the row kernel whatever their density: their panels sit in L2 / Infinity Cache
+// (tools/crossover.py, k = 50: f32 ties at 1e7 entries and the staged path wins by 18 % at 1.6e7; f64 wins by 27 % at 1e7).
+// Returns the panel leading dimension of the tile geometry, 0 for the row kernel.
+template <typename T>
+int staged_sweep_ldp(int64_t rows, int64_t cols, double entries, int64_t l, int spmm_variant) {
+  if (spmm_variant == 1 || rows <= 0 || cols <= 0 || l < 1 || l > k::kMaxPanelWidth) return 0;
+  const int ldp = sizeof(T) == 4 ? k::tiled_geometry((int)l) : 64;
+  const double row_bytes = (double)ldp * sizeof(T);
+  const double tile_bytes = 80.0 * 1024.0, block_rows = row_bytes == 256.0 ? 512.0 : 256.0;
+  const double chunks = std::ceil((double)rows / block_rows) * std::ceil((double)cols * row_bytes / tile_bytes);
+  double floor_entries = sizeof(T) == 4 ? 1e7 : 5e6;
+  if (const char* e = dbg_env("SAPCA_TILED_MIN_ENTRIES")) floor_entries = atof(e);   // tests: shards either side of the floor
+  const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes && entries >= floor_entries;
+  return (spmm_variant == 2 || dense_enough) ? ldp : 0;
+}
+
 enum Cat { C_PREPARE, C_STATS, C_SPMM, C_SPMMT, C_ORTHO, C_SMALL, C_LANCZOS, C_TRANSFORM, C_COMM, C_COUNT };
 
 struct Scope {
@@ -111,30 +131,13 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   h.stats_on_side = false;
   h.lz_scatter = false;
 
-  // LDS-staged sweep (f32, randomized): decided here because it fixes the order in which the transposed
-  // rows are produced.  It refills an 80 KiB panel tile per (row block, column tile) chunk and only beats
-  // the row-gather kernel when a chunk carries enough entries to amortise that fill (measured: 64 tile
-  // bytes per entry or less -> clearly faster; 164 -> no gain, 4x the prepare time).
+  // LDS-staged sweep (randomized fits): decided here because it fixes the order in which the transposed rows are produced
+  // (staged_sweep_ldp above has the break-even).
   int tiled_ldp = 0;
-  if (h.opt.spmm_variant != 1 && h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
+  if (h.opt.method == SAPCA_RANDOM && m > 0 && n > 0) {
     const int64_t n_kept = masked ? (int64_t)std::count_if(h.mask.begin(), h.mask.end(), [](uint8_t b) { return b != 0; }) : n;
     const int64_t l = std::min<int64_t>((int64_t)(h.opt.n_components + h.opt.n_oversamples), std::min<int64_t>(m, n_kept));
-    if (l >= 1 && l <= k::kMaxPanelWidth && n_kept > 0) {
-      const int ldp = sizeof(T) == 4 ? k::tiled_geometry((int)l) : 64;
-      const double row_bytes = (double)ldp * sizeof(T);
-      const double tile_bytes = 80.0 * 1024.0, block_rows = row_bytes == 256.0 ? 512.0 : 256.0;
-      const double chunks = std::ceil((double)m / block_rows) * std::ceil((double)n_kept * row_bytes / tile_bytes);
-      // f64: the row kernel gathers 512 bytes per entry, the staged sweep pays off a little earlier (200k x 20k at
-      // 3 %: 67 tile bytes per entry, 5.4 -> 1.9 ms per sweep).  Small operators stay on the row kernel: their panels
-      // sit in L2 / Infinity Cache and the format build and per-workgroup tile refills cost more than the gather
-      // (tools/crossover.py, k = 50: f32 ties at 1e7 entries and the staged path wins by 18 % at 1.6e7; f64 wins by
-      // 27 % at 1e7 and loses at 1e6).
-      const double entries = (double)nnz * ((double)n_kept / (double)n);
-      double floor_entries = sizeof(T) == 4 ? 1e7 : 5e6;
-      if (const char* e = dbg_env("SAPCA_TILED_MIN_ENTRIES")) floor_entries = atof(e);   // tests: shards either side of the floor
-      const bool dense_enough = entries * (sizeof(T) == 4 ? 64.0 : 96.0) >= chunks * tile_bytes && entries >= floor_entries;
-      if (h.opt.spmm_variant == 2 || dense_enough) tiled_ldp = ldp;
-    }
+    if (n_kept > 0) tiled_ldp = staged_sweep_ldp<T>(m, n_kept, (double)nnz * ((double)n_kept / (double)n), l, h.opt.spmm_variant);
   }
   const bool from_at = dbg_env("SAPCA_TILED_FROM_A") == nullptr;   // A^T's format from the transposed CSR (default) or straight from A
   const bool at_tile_major = tiled_ldp != 0 && from_at && dbg_env("SAPCA_AT_NATURAL") == nullptr;
@@ -1188,6 +1191,26 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
         d_cnt = h.stats.as<double>((size_t)3 * n + 1) + 2 * n;
         k::column_counts_f64(A.idx, A.nnz, n, d_cnt, h.scratch, s);
         if (h.comm.active()) h.comm.allreduce(d_cnt, (uint64_t)n, 1, s);
+      }
+    }
+    // A matrix the handle holds no preparation of (a separate transform of new rows, or of caller-owned arrays): above the
+    // staged sweep's break-even its tile-major format is built for this one sweep -- 0.9 ms + a 0.55 ms sweep at C2's size
+    // against 5 ms through the row kernel.  (The masked Q3 projection checks on its own whether it can use it.)
+    if (!top && !prepared && k <= k::kMaxPanelWidth && Au.nnz > 0) {
+      const int ldp_t = staged_sweep_ldp<T>(Au.rows, Au.cols, (double)Au.nnz, k, h.opt.spmm_variant);
+      if (ldp_t != 0) {
+        h.prep_key.valid = false;   // (tiled_a no longer belongs to the fitted matrix)
+        h.tiled_at = TiledOp();
+        h.tiled_a = TiledOp();
+        bool ok;
+        if constexpr (sizeof(T) == 4) ok = k::build_tiled(Au, false, ldp_t, h.tiled_a, h.tb_a, s);
+        else ok = k::build_tiled(Au, ldp_t, h.tiled_a, h.tb_a, s);
+        if (ok && h.tiled_a.valid) {
+          top = &h.tiled_a;
+          ldk = k > 128 ? (int)round_up(k, 64) : std::max(top->ldp, k <= 64 ? 64 : 128);
+        } else {
+          h.tiled_a = TiledOp();
+        }
       }
     }
     const T* mu = h.mean_used_dev.ptr<T>();

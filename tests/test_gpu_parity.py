@@ -1225,6 +1225,32 @@ def test_transform_of_a_matrix_that_was_not_fitted(dtype):
                       sp.csr_matrix((10, n + 1), dtype=dtype))
 
 
+def test_transform_of_a_large_matrix_that_was_not_fitted_builds_its_own_format():
+    """transform(B) with B != the fitted matrix and B above the staged sweep's break-even (here forced: spmm_variant 2): the
+    projection builds B's tile-major format for its one sweep instead of falling back to the row kernel (5 ms against 1.5 at
+    C2's size).  Same numbers as the row kernel's, Q2 counts from B, mean from the fit; masked: Q3 through the same format."""
+    m, n, k = 9000, 2600, 8
+    a = csr_np(synth.gapped_csr(m, n, 0.04, k, seed=3, dtype=torch.float32))
+    b = csr_np(synth.gapped_csr(5000, n, 0.05, k, seed=4, dtype=torch.float32))
+    A, B = mat(a[0], a[1], a[2], m, n), mat(b[0], b[1], b[2], 5000, n)
+    for variant in (2, 1):   # the tile-major format built for B; the row kernel
+        pca = _builder(k, 6, 2).spmm_variant(variant).build()
+        pca.fit(A)
+        t = pca.transform(B)
+        want = O.transform_sparse(b[0], b[1], b[2].astype(np.float64), 5000, n, pca.components_(np.float64), pca.mean_(np.float64), True)
+        np.testing.assert_allclose(t, want, atol=2e-4 * np.abs(want).max())
+        # the handle still fits and projects its own matrix afterwards (B's format does not pass for A's)
+        t2 = pca.fit_transform(A)
+        want2 = O.transform_sparse(a[0], a[1], a[2].astype(np.float64), m, n, pca.components_(np.float64), pca.mean_(np.float64), True)
+        np.testing.assert_allclose(t2, want2, atol=2e-4 * np.abs(want2).max())
+    mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
+    mp_ = sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).spmm_variant(2).svd_method(SVDMethod.Random(6, 2)).build()
+    mp_.fit(A)
+    tm = mp_.transform(B)
+    want_m = O.transform_masked_fast(b[0], b[1], b[2].astype(np.float64), 5000, n, mp_.components_(np.float64), mp_.mean_(np.float64), True, mask)
+    np.testing.assert_allclose(tm, want_m, atol=2e-4 * np.abs(want_m).max())
+
+
 def test_transform_after_the_values_were_edited_in_place():
     """fit(X) on caller-owned device arrays, X.values edited in place through torch, transform(X): the projection must
     see the new values (the preparation kept from the fit -- a tile-major copy of the values -- is not reused across
