@@ -470,11 +470,18 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       h.stats_on_side = true;   // (the chain itself is queued at the end of prepare())
       return;
     }
-    h.m_local = (double)m;   // (a member: the copy may still be reading it when this function has returned)
-    SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &h.m_local, sizeof(double), hipMemcpyHostToDevice, s));
-    if (h.comm.active()) { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s); }
-    SAPCA_HIP(hipMemcpyAsync(sums, d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
-    SAPCA_HIP(hipMemcpyAsync(sums + 2 * n, d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h.comm.active()) {
+      // the global row count rides along in the statistics' all-reduce
+      h.m_local = (double)m;   // (a member: the copy may still be reading it when this function has returned)
+      SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &h.m_local, sizeof(double), hipMemcpyHostToDevice, s));
+      { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s); }
+      SAPCA_HIP(hipMemcpyAsync(sums, d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+      SAPCA_HIP(hipMemcpyAsync(sums + 2 * n, d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
+    } else {
+      // one rank: the count is m -- no 8-byte copies in either direction in front of the first sweep (each a ~15 us hole)
+      sums[(size_t)2 * n] = (double)m;
+      SAPCA_HIP(hipMemcpyAsync(sums, d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
   };
   column_statistics(from_upload);
   h.stats_cols = n;
