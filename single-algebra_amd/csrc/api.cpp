@@ -287,7 +287,9 @@ sapca_status transform_device(sapca_handle h, uint64_t m, uint64_t n, uint64_t n
     SAPCA_CHECK(d_out != nullptr || m == 0, SAPCA_ERR_ARG, "null output buffer");
     CsrView<T> A = device_view<T>(m, n, nnz, p, i, v);
     T* host_out = out_on_host ? d_out : nullptr;
-    if (out_on_host) d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * h->opt.n_components, 1));
+    // (the staging holds what transform() writes and download_out() copies: m x k of the model that projects -- the one
+    // being fitted here has at most n_components, a fitted one has h->k)
+    if (out_on_host) d_out = h->out_tmp.as<T>(std::max<uint64_t>(m * std::max<uint64_t>(h->opt.n_components, fit_first ? 0 : h->k), 1));
     if (fit_first) {
       Engine<T>::fit(*h, A, true);
     } else if (static_cast<const void*>(v) != h->in_val.p) {

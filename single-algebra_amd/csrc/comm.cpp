@@ -87,15 +87,35 @@ void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
   std::memcpy(u.internal, id, 128);
   ncclComm_t c = nullptr;
   check(api().CommInitRank(&c, (int)nranks, u, (int)rank), "ncclCommInitRank");
-  rccl_comm = c;
+  rccl_comm.store(c);
   mode = RCCL;
   aborted.store(false);
   // the side stream's communicator: a collective split with one colour (every rank enters it right behind the init)
-  rccl_comm2 = nullptr;
+  rccl_comm2.store(nullptr);
+  ncclComm_t c2 = nullptr;
   if (api().CommSplit && dbg_env("SAPCA_COMM_NO_SPLIT") == nullptr) {
-    ncclComm_t c2 = nullptr;
-    if (api().CommSplit(c, 0, (int)rank, &c2, nullptr) == 0) rccl_comm2 = c2;
+    if (api().CommSplit(c, 0, (int)rank, &c2, nullptr) != 0) c2 = nullptr;
   }
+  // Every rank must see the same answer (a rank without the duplicate sweeps A^T in one piece and issues different
+  // collectives): one all-reduce on the main communicator counts the ranks whose split failed, and any failure drops the
+  // duplicate everywhere.  (Ranks whose library has no ncclCommSplit at all take part with "failed".)
+  float* d_flag = nullptr;
+  SAPCA_HIP(hipMalloc(&d_flag, sizeof(float)));
+  const float missing = c2 ? 0.f : 1.f;
+  float total = 1.f;
+  int rc = 0;
+  hipError_t he = hipMemcpy(d_flag, &missing, sizeof(float), hipMemcpyHostToDevice);
+  if (he == hipSuccess) rc = api().AllReduce(d_flag, d_flag, 1, kNcclFloat32, kNcclSum, c, nullptr);
+  if (he == hipSuccess && rc == 0) he = hipStreamSynchronize(nullptr);
+  if (he == hipSuccess && rc == 0) he = hipMemcpy(&total, d_flag, sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_flag);
+  if (he != hipSuccess || rc != 0 || total != 0.f) {
+    if (c2 && api().CommDestroy) (void)api().CommDestroy(c2);
+    c2 = nullptr;
+  }
+  rccl_comm2.store(c2);
+  check(rc, "ncclAllReduce (side-lane agreement)");
+  SAPCA_HIP(he);
 }
 
 void Comm::set_callback(uint32_t nranks_, uint32_t rank_, sapca_allreduce_fn f, void* c) {
@@ -114,9 +134,11 @@ void Comm::allreduce(void* buf, uint64_t count, int dtype, hipStream_t s, int la
   if (aborted.load()) throw Error(SAPCA_ERR_COMM, "communicator aborted: a peer of this fit failed");
   auto t0 = std::chrono::steady_clock::now();
   if (mode == RCCL) {
-    SAPCA_CHECK(lane == 0 || rccl_comm2 != nullptr, SAPCA_ERR_COMM, "internal: no communicator for the side stream");
-    check(api().AllReduce(buf, buf, (size_t)count, dtype == 1 ? kNcclFloat64 : kNcclFloat32, kNcclSum, lane == 0 ? rccl_comm : rccl_comm2, s),
-          "ncclAllReduce");
+    std::lock_guard<std::timed_mutex> issue(issue_mu);   // abort() swaps the communicators out only between two enqueues
+    void* const c = (lane == 0 ? rccl_comm : rccl_comm2).load();
+    if (aborted.load() || (lane == 0 && c == nullptr)) throw Error(SAPCA_ERR_COMM, "communicator aborted: a peer of this fit failed");
+    SAPCA_CHECK(c != nullptr, SAPCA_ERR_COMM, "internal: no communicator for the side stream");
+    check(api().AllReduce(buf, buf, (size_t)count, dtype == 1 ? kNcclFloat64 : kNcclFloat32, kNcclSum, c, s), "ncclAllReduce");
   } else if (mode == CALLBACK) {
     if (fn(ctx, buf, count, dtype, (void*)s) != 0) throw Error(SAPCA_ERR_COMM, "all-reduce callback reported failure");
   } else {
@@ -128,11 +150,13 @@ void Comm::allreduce(void* buf, uint64_t count, int dtype, hipStream_t s, int la
 void Comm::abort() {
   if (aborted.exchange(true)) return;
   if (mode != RCCL || !api().CommAbort) return;
-  // (ncclCommAbort frees the communicator: destroy() must not touch it again)
-  void* c2 = rccl_comm2;
-  void* c1 = rccl_comm;
-  rccl_comm2 = nullptr;
-  rccl_comm = nullptr;
+  // (ncclCommAbort frees the communicator: nobody may touch it again -- the pointers are taken out under the enqueue lock,
+  // or without it when the owning thread has been inside an enqueue for 250 ms: that is the hang this call ends)
+  std::unique_lock<std::timed_mutex> issue(issue_mu, std::defer_lock);
+  (void)issue.try_lock_for(std::chrono::milliseconds(250));
+  void* c2 = rccl_comm2.exchange(nullptr);
+  void* c1 = rccl_comm.exchange(nullptr);
+  if (issue.owns_lock()) issue.unlock();
   if (c2) (void)api().CommAbort(c2);
   if (c1) (void)api().CommAbort(c1);
 }
@@ -141,17 +165,26 @@ int Comm::async_error() {
   if (aborted.load()) return -1;
   if (mode != RCCL || !api().CommGetAsyncError) return 0;
   int e = 0;
-  if (rccl_comm && api().CommGetAsyncError(rccl_comm, &e) == 0 && e != 0) return e;
-  if (rccl_comm2 && api().CommGetAsyncError(rccl_comm2, &e) == 0 && e != 0) return e;
+  std::lock_guard<std::timed_mutex> issue(issue_mu);   // (abort() frees the communicators: not while they are being asked)
+  void* const c1 = rccl_comm.load();
+  void* const c2 = rccl_comm2.load();
+  if (aborted.load()) return -1;
+  if (c1 && api().CommGetAsyncError(c1, &e) == 0 && e != 0) return e;
+  if (c2 && api().CommGetAsyncError(c2, &e) == 0 && e != 0) return e;
   return 0;
 }
 
 void Comm::destroy() {
-  if (mode == RCCL && rccl_comm2 && api().CommDestroy) (void)api().CommDestroy(rccl_comm2);
-  if (mode == RCCL && rccl_comm && api().CommDestroy) (void)api().CommDestroy(rccl_comm);
-  rccl_comm2 = nullptr;
+  void* c2;
+  void* c1;
+  {
+    std::lock_guard<std::timed_mutex> issue(issue_mu);
+    c2 = rccl_comm2.exchange(nullptr);
+    c1 = rccl_comm.exchange(nullptr);
+  }
+  if (mode == RCCL && c2 && api().CommDestroy) (void)api().CommDestroy(c2);
+  if (mode == RCCL && c1 && api().CommDestroy) (void)api().CommDestroy(c1);
   aborted.store(false);
-  rccl_comm = nullptr;
   fn = nullptr;
   ctx = nullptr;
   mode = NONE;

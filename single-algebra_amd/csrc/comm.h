@@ -5,16 +5,23 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace sapca {
 
 struct Comm {
   uint32_t nranks = 1, rank = 0;
   enum Mode { NONE, RCCL, CALLBACK } mode = NONE;
-  void* rccl_comm = nullptr;
+  // The communicators are read by the owning thread (allreduce, async_error, destroy) and swapped out by abort() from ANY
+  // thread: atomics, and `issue_mu` is held across an enqueue so that abort() frees a communicator only between two of them
+  // (or after waiting 250 ms for an enqueue that never returns -- the case ncclCommAbort exists for).
+  std::atomic<void*> rccl_comm{nullptr};
   // a duplicate of the communicator (ncclCommSplit, all ranks one colour) for collectives issued on a second stream: the
   // first piece's all-reduce of a two-piece A^T sweep runs behind the second piece's sweep (engine.cpp); two streams must
   // not issue on one communicator.  Null when the library has no ncclCommSplit: the sweep then runs in one piece.
-  void* rccl_comm2 = nullptr;
+  std::atomic<void*> rccl_comm2{nullptr};
+  std::timed_mutex issue_mu;
   std::atomic<bool> aborted{false};   // abort() was called: every later collective fails at once with SAPCA_ERR_COMM
   sapca_allreduce_fn fn = nullptr;
   void* ctx = nullptr;
@@ -26,7 +33,7 @@ struct Comm {
   // dtype: 0 = f32, 1 = f64.  In place on a device buffer, ordered on `s`.
   // lane 1: the side stream's communicator (RCCL); the callback transports take any stream
   void allreduce(void* buf, uint64_t count, int dtype, hipStream_t s, int lane = 0);
-  bool has_side_lane() const { return mode == CALLBACK || (mode == RCCL && rccl_comm2 != nullptr); }
+  bool has_side_lane() const { return mode == CALLBACK || (mode == RCCL && rccl_comm2.load() != nullptr); }
   // Ends every collective this rank has in flight or will issue (ncclCommAbort on both communicators): kernels of a
   // collective a failed peer never joins return, and so do the stream waits behind them.  Callable from any thread.  The
   // communicator is unusable afterwards (init again).

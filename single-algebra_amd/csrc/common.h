@@ -130,6 +130,7 @@ struct TiledOp {
   int tile_bytes = 0;       // LDS bytes of one panel tile (the entry staging takes the rest of the 160 KiB)
   int64_t max_chunk = 0;    // most entries of one (row block, tile): the staged-entry kernels need it to fit their LDS staging
   const int32_t* blk_row0 = nullptr;   // [nrb+1] slot positions
+  int64_t mid_row0 = -1;               // blk_row0[nrb / 2] on the host (the cut of a sweep in two pieces); -1: not recorded
   const uint32_t* row_perm = nullptr;  // [rows] slot position -> row (rows sorted by length, longest first); null = identity
   const int64_t* chunk_off = nullptr;  // [nrb*nct+1] entry offsets
   const uint32_t* wave_off = nullptr;  // [nrb*nct][8]

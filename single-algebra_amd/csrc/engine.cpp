@@ -261,7 +261,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       }
       if (!h.ev_drop) SAPCA_HIP(hipEventCreateWithFlags(&h.ev_drop, hipEventDisableTiming));
       side_stats = !h.comm.active() && dbg_env("SAPCA_MASK_STATS_INLINE") == nullptr;
-      double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+      double* d_stats = h.stats.as<double>((size_t)3 * n + 1 + H::kStatsTail);
       SAPCA_HIP(hipMemsetAsync(d_stats + 2 * n, 0, (size_t)n * sizeof(double), s));
       if (!side_stats) {
         SAPCA_HIP(hipEventRecord(h.ev_drop, s));   // (the compaction synchronised: this only orders the side stream after it)
@@ -333,7 +333,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
       }
       Scope sc(h, C_PREPARE);
       int64_t* at_ptr = h.at_ptr.as<int64_t>((size_t)n + 1);
-      double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+      double* d_stats = h.stats.as<double>((size_t)3 * n + 1 + H::kStatsTail);
       h.tiled_at = TiledOp();
       at_direct = k::build_tiled_at_direct(A, tiled_ldp, h.tiled_at, h.tb_at, at_ptr, from_upload ? nullptr : d_stats, h.scratch, s);
       if (at_direct) { At.rows = n; At.cols = m; At.nnz = nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr; }
@@ -344,7 +344,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   if constexpr (sizeof(T) == 4) {
     if (compaction_done && try_masked_direct && nnz_used > 0) {
       Scope sc(h, C_PREPARE);
-      double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+      double* d_stats = h.stats.as<double>((size_t)3 * n + 1 + H::kStatsTail);
       int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
       double* d_part = h.scratch2.as<double>((size_t)2 * n_used + 2);   // sums | sums of squares of the kept columns, compact numbering
       h.tiled_at = TiledOp();
@@ -367,7 +367,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   bool masked_compact = false;
   if (compaction_done && !masked_direct && !lz_scatter) {
     Scope sc(h, C_PREPARE);
-    double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+    double* d_stats = h.stats.as<double>((size_t)3 * n + 1 + H::kStatsTail);
     int64_t* cat_ptr = h.cat_ptr.as<int64_t>((size_t)n_used + 1);
     int32_t* cat_idx = h.cat_idx.as<int32_t>((size_t)std::max<int64_t>(nnz, 1));
     T* cat_val = h.cat_val.as<T>((size_t)std::max<int64_t>(nnz, 1));
@@ -422,7 +422,7 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   double* sums = static_cast<double*>(h.stats_host.ensure(((size_t)2 * n + 1) * sizeof(double)));
   auto column_statistics = [&](bool uploaded) {
     Scope sc(h, C_STATS);
-    double* d_stats = h.stats.as<double>((size_t)3 * n + 1);
+    double* d_stats = h.stats.as<double>((size_t)3 * n + 1 + H::kStatsTail);
     if (uploaded) {
       SAPCA_HIP(hipMemcpyAsync(d_stats, h.up_stats.out.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
     } else if (lz_scatter) {
@@ -472,11 +472,22 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
     }
     if (h.comm.active()) {
       // the global row count rides along in the statistics' all-reduce
-      h.m_local = (double)m;   // (a member: the copy may still be reading it when this function has returned)
-      SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, &h.m_local, sizeof(double), hipMemcpyHostToDevice, s));
-      { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + 1, 1, s); }
+      // ... and so does this rank's vote on where the two-piece A^T sweep cuts the panel (fit_randomized), when its A^T format
+      // exists by now (the bucket / gather route builds it in front of the statistics): tail = {rows, ranks that voted, votes}
+      double* tail = h.stats_tail;   // (a member: the copy may still be reading it when this function has returned)
+      const uint32_t nr = h.comm.nranks;
+      const bool ride = vote_rides(h);
+      const size_t ntail = 1 + (ride ? (size_t)nr + 1 : 0);
+      std::fill(tail, tail + ntail, 0.0);
+      tail[0] = (double)m;
+      if (ride && h.tiled_at.valid) {
+        tail[1] = 1.0;
+        tail[2 + h.comm.rank] = (double)piece_vote(h, h.tiled_at.ldp);
+      }
+      SAPCA_HIP(hipMemcpyAsync(d_stats + 3 * n, tail, ntail * sizeof(double), hipMemcpyHostToDevice, s));
+      { Scope cs(h, C_COMM); h.comm.allreduce(d_stats, (uint64_t)3 * n + ntail, 1, s); }
       SAPCA_HIP(hipMemcpyAsync(sums, d_stats, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, s));
-      SAPCA_HIP(hipMemcpyAsync(sums + 2 * n, d_stats + 3 * n, sizeof(double), hipMemcpyDeviceToHost, s));
+      SAPCA_HIP(hipMemcpyAsync(tail, d_stats + 3 * n, ntail * sizeof(double), hipMemcpyDeviceToHost, s));
     } else {
       // one rank: the count is m -- no 8-byte copies in either direction in front of the first sweep (each a ~15 us hole)
       sums[(size_t)2 * n] = (double)m;
@@ -485,8 +496,14 @@ void Engine<T>::prepare(H& h, const CsrView<T>& A) {
   };
   column_statistics(from_upload);
   h.stats_cols = n;
+  h.vote_ready = false;
   if (h.comm.active()) {   // the global row count is the sum over the ranks: needed on the host now
     SAPCA_HIP(hipStreamSynchronize(s));
+    sums[(size_t)2 * n] = h.stats_tail[0];
+    if (vote_rides(h) && (uint32_t)std::llround(h.stats_tail[1]) == h.comm.nranks) {
+      h.vote_cut = (int64_t)*std::min_element(h.stats_tail + 2, h.stats_tail + 2 + h.comm.nranks);
+      h.vote_ready = true;
+    }
     h.m_global = (uint64_t)std::llround(sums[(size_t)2 * n]);
     h.stats_pending = false;
     finish_statistics(h);
@@ -688,6 +705,22 @@ void Engine<T>::normalize(H& h, T* P, int64_t rows, int l, int ld, int normalize
   }
 }
 
+template <typename T>
+bool Engine<T>::vote_rides(const H& h) {
+  return sizeof(T) == 4 && h.comm.active() && h.opt.method == SAPCA_RANDOM && h.opt.spmm_variant != 1 &&
+         (size_t)h.comm.nranks + 2 <= H::kStatsTail;
+}
+
+template <typename T>
+int64_t Engine<T>::piece_vote(H& h, int ld) {
+  const char* ov = getenv("SAPCA_AT_OVERLAP");   // (read per fit: the tests switch it)
+  const bool enabled = ov != nullptr ? atoi(ov) != 0 : h.comm.mode != Comm::RCCL;
+  if (!enabled || !h.comm.has_side_lane() || !k::spmm_tiled_pieces_ok(h.tiled_at, 2, ld)) return 0;
+  std::vector<int64_t> b;
+  k::spmm_tiled_piece_bounds(h.tiled_at, 2, b, h.stream);
+  return b[1];
+}
+
 // ------------------------------------------------------------------------------------------
 // R7-R11, R13: randomized SVD of the (implicitly centred) prepared operator.
 // ------------------------------------------------------------------------------------------
@@ -757,26 +790,34 @@ void Engine<T>::fit_randomized(H& h) {
   int piece_wgs = 240;
   h.at_sweep_pieces = 1u;
   if constexpr (sizeof(T) == 4) {
-    // Default: on wherever the side stream has a lane of its own -- the callback / in-process transports, and RCCL through the
-    // duplicate communicator made at init (two streams never issue on one communicator).  SAPCA_AT_OVERLAP=0 switches it off.
-    const char* ov = getenv("SAPCA_AT_OVERLAP");   // (read per fit: the tests switch it)
-    const bool overlap_off = (ov != nullptr && atoi(ov) == 0) || !h.comm.has_side_lane();
-    if (h.comm.active() && !overlap_off && variant != 1) {
+    // On by default wherever the side stream has a lane of its own and the path has run with several ranks: the callback /
+    // in-process transports.  Under RCCL (the duplicate communicator made at init: two streams never issue on one
+    // communicator) it is opt-in, SAPCA_AT_OVERLAP=1, until it has run on more than one GPU; SAPCA_AT_OVERLAP=0 switches it
+    // off everywhere.  Whether a rank takes part is ITS decision, so every rank of a multi-rank fit votes (0 = one piece)
+    // and nobody waits in a collective a peer never joins.
+    if (h.comm.active() && variant != 1) {
       // The pieces are whole row blocks of this rank's operator, and ranks cut their blocks differently (the block count
       // follows the shard's own tile count): the ranks agree on one row count -- the smallest first piece, 0 if any rank
-      // cannot sweep in pieces -- so that every rank's collectives have the same sizes.  One small all-reduce per fit.
+      // cannot or will not sweep in pieces -- so that every rank's collectives have the same sizes.  The votes came with the
+      // column statistics when every rank had its A^T format by then (no extra collective, no host round trip here);
+      // otherwise one small all-reduce.
       const bool mine = tiled && k::spmm_tiled_pieces_ok(h.tiled_at, 2, ld);
-      if (mine) k::spmm_tiled_piece_bounds(h.tiled_at, 2, piece_rows, s);
-      const uint32_t nr = h.comm.nranks;
-      std::vector<double> votes((size_t)nr, 0.0);
-      votes[h.comm.rank] = mine ? (double)piece_rows[1] : 0.0;
-      double* d_votes = h.votes.as<double>(nr);
-      SAPCA_HIP(hipMemcpyAsync(d_votes, votes.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
-      h.comm.allreduce(d_votes, nr, 1, s);
-      SAPCA_HIP(hipMemcpyAsync(votes.data(), d_votes, nr * sizeof(double), hipMemcpyDeviceToHost, s));
-      SAPCA_HIP(hipStreamSynchronize(s));
-      cut = (int64_t)*std::min_element(votes.begin(), votes.end());
+      if (h.vote_ready) {
+        cut = h.vote_cut;
+        SAPCA_CHECK(cut == 0 || mine, SAPCA_ERR_COMM, "internal: the ranks agreed on a two-piece A^T sweep this rank cannot run");
+      } else {
+        const uint32_t nr = h.comm.nranks;
+        std::vector<double> votes((size_t)nr, 0.0);
+        votes[h.comm.rank] = mine ? (double)piece_vote(h, ld) : 0.0;
+        double* d_votes = h.votes.as<double>(nr);
+        SAPCA_HIP(hipMemcpyAsync(d_votes, votes.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+        h.comm.allreduce(d_votes, nr, 1, s);
+        SAPCA_HIP(hipMemcpyAsync(votes.data(), d_votes, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        SAPCA_HIP(hipStreamSynchronize(s));
+        cut = (int64_t)*std::min_element(votes.begin(), votes.end());
+      }
       overlap = mine && cut > 0 && cut < n_used;
+      if (overlap) k::spmm_tiled_piece_bounds(h.tiled_at, 2, piece_rows, s);
     }
     h.at_sweep_pieces = overlap ? 2u : 1u;
     if (overlap) {
@@ -1017,8 +1058,10 @@ void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
   // strong-scaled fit gain 0.2 ms of a 9.5 ms step, a million rows on one GPU would lose as much (measured, round 4).
   {
     const double lw = (double)(h.opt.n_components + h.opt.n_oversamples) <= 64 ? 64.0 : 128.0;
+    // (decided from what every rank of a sharded fit sees alike -- the ranks' shards of one projection take one route;
+    // m_global is not known yet, the shard is about 1 / nranks of it)
     h.defer_small = defer_finish && h.mask.empty() && h.opt.method == SAPCA_RANDOM && sizeof(T) == 4 &&
-                    (double)A.rows * lw * lw <= 400e3 * 64.0 * 64.0;
+                    (h.comm.active() || (double)A.rows * lw * lw <= 400e3 * 64.0 * 64.0);
   }
   h.spans.clear();
   h.comm.host_ms = 0;
@@ -1195,7 +1238,7 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
       Au = A;
       if (ref_sem) {
         h.prep_key.valid = false;
-        d_cnt = h.stats.as<double>((size_t)3 * n + 1) + 2 * n;
+        d_cnt = h.stats.as<double>((size_t)3 * n + 1 + H::kStatsTail) + 2 * n;
         k::column_counts_f64(A.idx, A.nnz, n, d_cnt, h.scratch, s);
         if (h.comm.active()) h.comm.allreduce(d_cnt, (uint64_t)n, 1, s);
       }
@@ -1262,7 +1305,9 @@ void Engine<T>::transform(H& h, const CsrView<T>& A, T* d_out) {
         bool done = false;
         if constexpr (sizeof(T) == 4) {
           // the fitted matrix's tile-major format: A'W - P diag(mu) W as two sweeps (spmm_dq.hip)
-          if (center && top && h.opt.spmm_variant != 1 && !h.q3_cancels && dbg_env("SAPCA_Q3_ROWKERNEL") == nullptr) {
+          // (only for the fitted matrix: `q3_cancels` was decided from ITS column statistics; another matrix takes the row
+          // kernel, which subtracts entry by entry like the reference)
+          if (center && top && prepared && h.opt.spmm_variant != 1 && !h.q3_cancels && dbg_env("SAPCA_Q3_ROWKERNEL") == nullptr) {
             float* W2 = h.scratch2.as<float>((size_t)n_used * ldk);
             float* tmp = h.panel_y.as<float>((size_t)m * std::max(k, 1));
             done = k::q3_projection_dq(Au, *top, W, ldk, mu, W2, tmp, d_out, k, s);

@@ -77,7 +77,12 @@ struct sapca_handle_s {
   sapca::PinnedBuf lanczos_host;  // alpha | beta of the Lanczos tridiagonal, read back at each convergence check
   bool stats_pending = false;
   int64_t stats_cols = 0;
-  double m_local = 0;
+  // multi-rank fits: what rides behind the column statistics in their all-reduce -- {this rank's rows, ranks whose vote is
+  // in, one vote per rank on the cut of the two-piece A^T sweep} (engine.cpp, column_statistics / fit_randomized)
+  static constexpr size_t kStatsTail = 72;
+  double stats_tail[kStatsTail] = {};
+  bool vote_ready = false;        // every rank's vote came with the statistics: vote_cut is the agreed cut (0: one piece)
+  int64_t vote_cut = 0;
 
   // device buffers (grow-only)
   sapca::DevBuf in_ptr, in_idx, in_val, up64, up64i, out_tmp;    // host-entry uploads
@@ -129,6 +134,8 @@ struct Engine {
   static void transform(H& h, const CsrView<T>& A, T* d_out);
   static void fit_randomized(H& h);
   static void fit_lanczos(H& h);
+  static bool vote_rides(const H& h);          // the cut of the two-piece A^T sweep is agreed inside the statistics' all-reduce
+  static int64_t piece_vote(H& h, int ld);     // this rank's vote: the first output row of its second piece, 0 = one piece
   // normaliser on a rows x ld panel; R_out (ld x ld f64 device, may be null) receives the
   // accumulated upper factor of the last CholeskyQR2.
   static void normalize(H& h, T* P, int64_t rows, int l, int ld, int normalizer, bool sharded, double* R1, double* R2,

@@ -52,6 +52,8 @@ __host__ __device__ inline int dq_first(int wave, int nquads) { return wave * nq
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
+typedef unsigned v8u __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // One wave per (row block, tile): lane w < 16 computes the entry offset and chunk count of sweep wave w's stream, and the rank
 // of its step count among the four waves that share its SIMD (waves w, w + 4, w + 8, w + 12: the longest gets 3) -- the
@@ -91,7 +93,11 @@ __global__ void __launch_bounds__(DQ_THREADS)
 spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict__ perm, int nct,
                 const uint64_t* __restrict__ ent, const uint16_t* __restrict__ steps, const uint32_t* __restrict__ info,
                 int64_t panel_rows, const float* __restrict__ X, int ldx, int nsplit, int tiles_per_split,
-                float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec, int rb0) {
+                float* __restrict__ out, int64_t out_rows_total, int ldo, int ncols, const float* __restrict__ cvec, int rb0
+#ifdef DQ2_STAMPS
+                , uint32_t* __restrict__ stamps, int stamp_wgs
+#endif
+                ) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
@@ -103,6 +109,13 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
   const int my_rows = min(nrows, 4 * (quad0 + my_quads)) - 4 * quad0;
 
   v8f a0, a1, a2, a3, a4, a5, a6, a7;   // row slots 2i, 2i+1 (RG = 8: a0..a3)
+#ifdef DQ2_STAMPS
+  v8u st8 = v8u(0u);   // R0..R7 of tools/gen_spmm_dq2.py's stamp mode, lane = tile & 63
+  v4u st4 = v4u(0u);   // {-, R8, R10, -}
+#define DQ2_STAMP_OUTS , "=&{v[120:127]}"(st8), "=&{v[52:55]}"(st4)
+#else
+#define DQ2_STAMP_OUTS
+#endif
   if (ct0 < ct1) {
     const unsigned lds_base = (unsigned)(size_t)lds;
     unsigned lb = lds_base + q * 16, eoff = q * 32 + g * 8, l8 = lane * 8, l2 = lane * 2, l2c = min(lane, 15) * 2, col16 = q * 16;
@@ -125,12 +138,12 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
     if constexpr (RG == 8) {
       if constexpr (PAT)
         asm volatile(DQ2_MAIN_ASM_8_PAT
-                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)
+                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3) DQ2_STAMP_OUTS
                      : DQ2_INPUTS
                      : DQ2_MAIN_CLOBBERS_8);
       else
         asm volatile(DQ2_MAIN_ASM_8
-                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3)
+                     : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3) DQ2_STAMP_OUTS
                      : DQ2_INPUTS
                      : DQ2_MAIN_CLOBBERS_8);
       a4 = a5 = a6 = a7 = v8f(0.f);
@@ -138,13 +151,13 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
       if constexpr (PAT)
         asm volatile(DQ2_MAIN_ASM_16_PAT
                      : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3), "=&{v[88:95]}"(a4),
-                       "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7)
+                       "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7) DQ2_STAMP_OUTS
                      : DQ2_INPUTS
                      : DQ2_MAIN_CLOBBERS_16);
       else
         asm volatile(DQ2_MAIN_ASM_16
                      : "=&{v[56:63]}"(a0), "=&{v[64:71]}"(a1), "=&{v[72:79]}"(a2), "=&{v[80:87]}"(a3), "=&{v[88:95]}"(a4),
-                       "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7)
+                       "=&{v[96:103]}"(a5), "=&{v[104:111]}"(a6), "=&{v[112:119]}"(a7) DQ2_STAMP_OUTS
                      : DQ2_INPUTS
                      : DQ2_MAIN_CLOBBERS_16);
     }
@@ -153,6 +166,15 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
     a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = v8f(0.f);
   }
   const v8f acc2[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+#ifdef DQ2_STAMPS
+  if (stamps && (int)blockIdx.x < stamp_wgs) {   // [workgroup][wave][12 records][64 tiles]
+    uint32_t* w = stamps + (((size_t)blockIdx.x * DQ_WAVES + wave) * 12) * WAVE + lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j * WAVE] = st8[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[(8 + j) * WAVE] = st4[j];
+  }
+#endif
 
   // lane (g, q) holds columns 4q..4q+3 of row 4j+g of its wave
   float* dst_base = out + (nsplit > 1 ? (int64_t)sp * out_rows_total * ldo : 0);
@@ -302,6 +324,18 @@ void launch_dq_f64(const TiledOp& op, const double* X, int ldx, double* out, int
   SAPCA_HIP(hipGetLastError());
 }
 
+#ifdef DQ2_STAMPS
+// stamp builds only (tools/dq_stamps.sh): the side buffer of the launch to instrument, counted from the call below
+static uint32_t* g_stamp_buf = nullptr;
+static int g_stamp_wgs = 0, g_stamp_which = -1, g_stamp_launch = 0;
+extern "C" __attribute__((visibility("default"))) void sapca_debug_dq_stamps(void* dev_buf, int max_wgs, int which_launch) {
+  g_stamp_buf = static_cast<uint32_t*>(dev_buf);
+  g_stamp_wgs = max_wgs;
+  g_stamp_which = which_launch;
+  g_stamp_launch = 0;
+}
+#endif
+
 template <int RG>
 static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, int ldo, int ncols, const float* cvec, int flags,
                         hipStream_t s, int rb0, int rb1, int nsplit, int tiles_per_split) {
@@ -311,7 +345,11 @@ static void launch_dq_t(const TiledOp& op, const float* X, int ldx, float* out, 
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), DQ_LDS, a);
     hipLaunchKernelGGL(kern, dim3((unsigned)((rb1 - rb0) * nsplit)), dim3(DQ_THREADS), DQ_LDS, s, op.blk_row0, op.row_perm, op.nct,
                        reinterpret_cast<const uint64_t*>(op.ent), reinterpret_cast<const uint16_t*>(op.steps), op.dq_info, op.cols, X, ldx,
-                       nsplit, tiles_per_split, out, op.rows, ldo, ncols, cvec, rb0);
+                       nsplit, tiles_per_split, out, op.rows, ldo, ncols, cvec, rb0
+#ifdef DQ2_STAMPS
+                       , (g_stamp_launch++ == g_stamp_which) ? g_stamp_buf : nullptr, g_stamp_wgs
+#endif
+                       );
   };
   if (pat) launch(&spmm_dq_kernel<RG, true>, attr[1]);
   else launch(&spmm_dq_kernel<RG, false>, attr[0]);

@@ -2126,6 +2126,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   int tiles_per_split = 0;
   int64_t nchunks = 0, max_chunk = 0, total = 0;
   int32_t* d_blk = nullptr;
+  int64_t mid_row0 = -1;
   uint8_t* d_steps = nullptr;
   uint32_t* d_wave_off = nullptr;
   uint32_t* d_quad_off = nullptr;
@@ -2159,6 +2160,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       for (int64_t b = 0; b <= nrb; ++b) blk[(size_t)b] = (int32_t)(op_rows * b / nrb);
     }
     nchunks = nrb * nct;
+    mid_row0 = blk[(size_t)(nrb / 2)];
     d_blk = buf.blk.as<int32_t>((size_t)nrb + 1);
     d_steps = buf.steps.as<uint8_t>((size_t)nchunks * (quad ? (size_t)Q_BLOCK_QUADS * 2 : (size_t)BLOCK_ROWS));
     d_wave_off = buf.wave_off.as<uint32_t>((size_t)nchunks * waves);
@@ -2227,6 +2229,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   bool aux_pending = false;
   op.rows = op_rows; op.cols = op_cols; op.ldp = ldp_elems; op.elem = (int)sizeof(VT); op.tc = tc; op.nct = nct; op.nrb = (int)nrb; op.block_rows = block_rows; op.max_chunk = max_chunk;
   op.nsplit = nsplit; op.tiles_per_split = tiles_per_split; op.total_entries = total; op.slots = slots; op.fmt = quad ? 1 : 0; op.tile_bytes = tile_bytes;
+  op.mid_row0 = mid_row0;
   op.blk_row0 = d_blk; op.row_perm = d_perm; op.chunk_off = d_chunk; op.wave_off = d_wave_off; op.steps = d_steps; op.ent = d_ent;
   if constexpr (f32) {
     // the DPP-fed sweep's tables depend on the counts only: queued ahead of the fill (a small kernel that would otherwise wait
@@ -2512,6 +2515,10 @@ bool spmm_tiled_pieces_ok(const TiledOp& op, int npieces, int ldx) {
 
 // bounds[p] = first output row of piece p (bounds[npieces] = rows): one small copy from the device, synchronous
 void spmm_tiled_piece_bounds(const TiledOp& op, int npieces, std::vector<int64_t>& bounds, hipStream_t s) {
+  if (npieces == 2 && op.mid_row0 >= 0) {   // (the builder kept the one boundary on the host: no copy, no wait)
+    bounds = {0, op.mid_row0, op.rows};
+    return;
+  }
   std::vector<int32_t> b((size_t)npieces + 1);
   for (int p = 0; p <= npieces; ++p)
     SAPCA_HIP(hipMemcpyAsync(&b[(size_t)p], op.blk_row0 + (int64_t)op.nrb * p / npieces, sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -53,6 +53,22 @@ ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved wi
 B64 = os.environ.get("DQ2_B64", "0") != "0"     # one 64-bit row_newbcast move per step ({offset, value}) + a plain add, instead of add_dpp + mov_dpp
 FMAC = os.environ.get("DQ2_FMAC", "0") != "0"   # four v_fmac_f32 per step instead of two v_pk_fma_f32
 P64 = [[20, 22], [24, 26]]                        # B64: even-aligned pairs, lo becomes the LDS address, hi is the value
+# DQ2_STAMPS=1 (debug builds only: tools/dq2_variant.sh stamps DQ2_STAMPS=1, tools/dq_stamps.py): s_memtime stamps where a wave
+# can wait, kept in lanes of spare VGPRs (lane = tile & 63) and handed to the kernel's epilogue, which writes them to a side
+# buffer.  Per (wave, tile): R0 tile top, R1 before the wait for this wave's LDS-DMA pieces, R2 pieces landed = barrier arrive,
+# R3 barrier leave, R4 first chunk entered, R5 tile done; sums over the tile's chunks: R6 the time spent at `s_waitcnt vmcnt(2)`
+# (entry loads), R7 one LDS round trip per chunk (C: group 0's reads issued -> D: position 0's wait for them over), R9 the
+# wave's own time between the two (C -> E: it arrives at that wait; R7 - R9 = what position 0 waited), R10 the wait of
+# position 4 (steady state: its reads were issued one position earlier); R8 = chunks.  A stamp issued in front of a wait
+# counts in lgkmcnt itself, so a measured LDS wait is at least one SMEM latency (the floor shows in R6 of chunks whose
+# entries had long arrived).  f32 sweeps only.
+STAMPS = os.environ.get("DQ2_STAMPS", "0") != "0"
+ST_A, ST_B = 98, 100           # s[98:99], s[100:101]: stamp pairs (free in the plain kernel)
+ST_E, ST_E4, ST_D4 = 74, 64, 76   # s[74:75], s[64:65], s[76:77]: stamps before position 0's wait, before / after position 4's
+ST_SVM, ST_SL, ST_SOWN, ST_SP4 = 37, 39, 46, 60   # scalar accumulators of a tile
+ST_R = 120                     # v[120:127] = R0..R7
+ST_R8, ST_R9, ST_R10 = 53, 54, 55   # (+ v51, v52 unused; v[52:55] leaves the block as one operand)
+
 
 F64 = False       # set per variant in main(): the f64 sweep (16-byte entries, 512-byte panel rows, four f64 columns per lane)
 ACCW = 4          # accumulator registers per row slot (8 for f64)
@@ -115,6 +131,29 @@ _uid = [0]
 def uid(prefix):
     _uid[0] += 1
     return f"{prefix}{_uid[0]}"
+
+
+def stamp(L, reg):
+    """s_memtime -> lane (tile & 63) of v[reg]; only at points where no LDS read is in flight"""
+    if not STAMPS:
+        return
+    L += [f"s_memtime s[{ST_A}:{ST_A + 1}]", f"s_and_b32 s{ST_B}, s{S_T}, 63", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 m0, s{ST_B}", "s_nop 3",
+          f"v_writelane_b32 v{reg}, s{ST_A}, m0"]
+
+
+def stamp_lds_sample_close(L):
+    """the samples of the chunk that just ended (every pair is zero when there was none): D - C, E - C, D4 - E4"""
+    L += [f"s_sub_u32 s{ST_B}, s{ST_B}, s{ST_A}", f"s_add_u32 s{ST_SL}, s{ST_SL}, s{ST_B}",
+          f"s_sub_u32 s{ST_E}, s{ST_E}, s{ST_A}", f"s_add_u32 s{ST_SOWN}, s{ST_SOWN}, s{ST_E}",
+          f"s_sub_u32 s{ST_D4}, s{ST_D4}, s{ST_E4}", f"s_add_u32 s{ST_SP4}, s{ST_SP4}, s{ST_D4}",
+          f"s_mov_b64 s[{ST_E4}:{ST_E4 + 1}], 0", f"s_mov_b64 s[{ST_D4}:{ST_D4 + 1}], 0"]   # (a chunk may end before position 4)
+
+
+def stamp_pairs_clear(L):
+    for pr in (ST_A, ST_B, ST_E, ST_E4, ST_D4):
+        L.append(f"s_mov_b64 s[{pr}:{pr + 1}], 0")
+    for a in (ST_SVM, ST_SL, ST_SOWN, ST_SP4):
+        L.append(f"s_mov_b32 s{a}, 0")
 
 
 def grp_a_parts(k):
@@ -262,7 +301,11 @@ def bodies(L):
         for k in range(8):
             L.append(f"body_{s}_{k}:")
             ahead = min(DEPTH, 8 - k) - 1
+            if STAMPS and k in (0, 4):
+                L.append(f"s_memtime s[{ST_E if k == 0 else ST_E4}:{(ST_E if k == 0 else ST_E4) + 1}]")
             L.append(f"s_waitcnt lgkmcnt({(4 if F64 else 2) * ahead})")
+            if STAMPS and k in (0, 4):
+                L.append(f"s_memtime s[{ST_B if k == 0 else ST_D4}:{(ST_B if k == 0 else ST_D4) + 1}]")
             f0, f1 = grp_fma_parts(s, k)
             if ODD:
                 L += f0
@@ -327,7 +370,12 @@ def chunk_routines(L, pattern):
     for r in range(3):
         e = EB[r]
         L.append(f"ctl_{r}:")
+        if STAMPS:   # (no LDS read is in flight here: position 7 waited for the chunk's last)
+            stamp_lds_sample_close(L)
+            L.append(f"s_memtime s[{ST_A}:{ST_A + 1}]")
         L.append("s_waitcnt vmcnt(2)")
+        if STAMPS:
+            L += [f"s_memtime s[{ST_B}:{ST_B + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 s{ST_B}, s{ST_B}, s{ST_A}", f"s_add_u32 s{ST_SVM}, s{ST_SVM}, s{ST_B}"]
         if F64:
             L += [f"v_mov_b32 v{ECUR[0]}, v{e[0]}", f"v_mov_b32 v{ECUR[0] + 2}, v{e[0] + 2}", f"v_mov_b32 v{ECUR[0] + 3}, v{e[0] + 3}"]
         else:
@@ -346,6 +394,8 @@ def chunk_routines(L, pattern):
               f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[(r + 1) % 3]}:{S_CTLA[(r + 1) % 3] + 1}]"]
         for k in range(DEPTH):
             grp_a(k, L)
+            if STAMPS and k == 0:
+                L.append(f"s_memtime s[{ST_A}:{ST_A + 1}]")
         L.append(f"s_setpc_b64 s[{S_RET}:{S_RET + 1}]")
     for r in range(3):
         e = EB[r]
@@ -368,6 +418,9 @@ def body(pattern):
     # accumulators <- 0
     for i in range(ACCW * RG):
         L.append(f"v_mov_b32 v{ACC + i}, 0")
+    if STAMPS:
+        for v in list(range(ST_R, ST_R + 8)) + [52, ST_R8, ST_R9, ST_R10]:
+            L.append(f"v_mov_b32 v{v}, 0")
     L += [f"s_mov_b32 s{S_T}, 0", f"s_mov_b32 s{S_NT}, %[ntiles]", f"s_mov_b32 s{S_TABS}, %[t0]",
           f"s_mov_b32 s{S_BUF}, 0", f"s_mov_b64 s[{S_INFO}:{S_INFO + 1}], %[info]", f"s_lshl_b32 s{S_4NCT}, %[nct], {2 if RPP == 4 else 1}",   # panel rows a piece advances by: RPP * nct
           f"s_add_u32 s{S_TLAST}, %[t0], %[ntiles]", f"s_sub_u32 s{S_TLAST}, s{S_TLAST}, 1",
@@ -390,6 +443,7 @@ def body(pattern):
     dma_piece(L)
     L += [f"s_cmp_lg_u32 s{S_NP}, 0", "s_cbranch_scc1 first_pieces", "s_waitcnt vmcnt(0)"]
     L += ["tile_top:"]   # ---- tile loop
+    stamp(L, ST_R + 0)
     # a new 64-tile window of the info table (tiles are never linked across windows)
     L += [f"s_and_b32 s{S_A}, s{S_T}, 63", f"s_cmp_lg_u32 s{S_A}, 0", "s_cbranch_scc1 same_window", f"s_cmp_eq_u32 s{S_T}, 0",
           "s_cbranch_scc1 same_window", f"s_add_u32 s{S_INFO}, s{S_INFO}, 0x200", f"s_addc_u32 s{S_INFO + 1}, s{S_INFO + 1}, 0",
@@ -417,8 +471,11 @@ def body(pattern):
     L.append(f"global_load_ushort v{VCNT2}, %[l2c], s[{S_STP}:{S_STP + 1}]")
     L += [f"s_add_u32 s{S_ND}, s{S_ND}, 4", f"s_mov_b32 s{S_BASE}, 0", "preloaded:"]
     # this wave's pieces of the tile have landed: wait for all but what was issued after the last of them
+    stamp(L, ST_R + 1)
     wait_vmcnt(L, S_ND, 6)
+    stamp(L, ST_R + 2)
     L += ["s_barrier"]
+    stamp(L, ST_R + 3)
     # the step counts (issued before the last three entry loads of a linked predecessor); everything of a tile that loaded its own
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 cnt_pre", "s_waitcnt vmcnt(0)", "s_branch cnt_ok", "cnt_pre:", "s_waitcnt vmcnt(3)", "cnt_ok:"]
     L += [f"v_mov_b32 v{VCNT}, v{VCNT2}" if ODD else f"v_lshrrev_b32 v{VCNT}, 1, v{VCNT2}", f"v_add_u32 v{VCNT}, -1, v{VCNT}", f"s_mov_b64 vcc, s[{S_QM}:{S_QM + 1}]",
@@ -432,11 +489,20 @@ def body(pattern):
     L += [f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[0]}:{S_CTLA[0] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 0", "s_cbranch_scc1 ctl_set",
           f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[1]}:{S_CTLA[1] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 ctl_set",
           f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[2]}:{S_CTLA[2] + 1}]", "ctl_set:"]
+    stamp(L, ST_R + 4)
+    if STAMPS:
+        stamp_pairs_clear(L)
     L += [f"s_cmp_eq_u32 s{S_NCH}, 0", "s_cbranch_scc1 tile_done", "s_branch enter_0"]
     bodies(L)
     stubs(L)
     chunk_routines(L, pattern)
     L += ["tile_done:", "s_waitcnt lgkmcnt(0)"]
+    if STAMPS:
+        stamp_lds_sample_close(L)
+        stamp(L, ST_R + 5)   # (leaves the tile's lane in m0)
+        for acc, rec in ((ST_SVM, ST_R + 6), (ST_SL, ST_R + 7), (ST_SOWN, ST_R9), (ST_SP4, ST_R10)):
+            L.append(f"v_writelane_b32 v{rec}, s{acc}, m0")
+        L.append(f"v_writelane_b32 v{ST_R8}, s{S_NCH}, m0")
     # pieces the chunks did not issue (fewer than five chunks)
     L += [f"s_cmp_eq_u32 s{S_NP}, 0", "s_cbranch_scc1 pieces_done", "more_pieces:"]
     dma_piece(L)
@@ -479,16 +545,20 @@ def clobbers():
     if DEPTH == 3:
         v += [f"v{i}" for i in range(50, 54)] + [f"v{i}" for i in range(ACC + 4 * RG, ACC + 4 * RG + 8)]
     s = [f"s{i}" for i in range(36, 98)]
+    if STAMPS:   # (v[120:127] and v[52:55] are outputs of the block, not clobbers)
+        s += [f"s{i}" for i in range(98, 102)]
     return v + s + ["memory", "scc", "m0", "vcc"]
 
 
 def main():
-    global RG
+    global RG, STAMPS
     here = os.path.dirname(os.path.abspath(__file__))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "single-algebra_amd", "csrc", "spmm_dq2_gen.h")
     with open(path, "w") as out:
         out.write("// generated by tools/gen_spmm_dq2.py -- do not edit; the generator documents the structure\n")
         out.write(f"#define DQ2_ACC_BASE {ACC}\n#define DQ2_TILE_BYTES {TILE_B}\n#define DQ2_ODD_STEPS {1 if ODD else 0}\n")
+        if STAMPS:
+            out.write("#define DQ2_STAMPS 1\n")
         for rg in (8, 16):   # 512-row and 1024-row blocks
             for pattern in (False, True):
                 RG = rg
@@ -504,6 +574,7 @@ def main():
             out.write(f"#define DQ2_MAIN_CLOBBERS_{rg} " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
         # the f64 sweep: four row slots per lane group (blocks of <= 256 rows, the f64 quad format's), accumulators from v80
         if not (B64 or FMAC or ILV or DEPTH != 2):
+            stamps_f32, STAMPS = STAMPS, False   # (the f64 sweep carries no stamps)
             RG = 4
             set_f64(True)
             _uid[0] = 0
@@ -515,6 +586,7 @@ def main():
             out.write("#define DQ2_MAIN_CLOBBERS_F64 " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
             print(f"wrote DQ2_MAIN_ASM_F64: {len(L)} lines")
             set_f64(False)
+            STAMPS = stamps_f32
 
 
 if __name__ == "__main__":
