@@ -8,8 +8,10 @@
 A "step" is one fit_transform of the hot path over a device-resident CSR (inputs already in
 HBM when the timed region starts).  At N=1 the workload is BASELINE.json configs[1] (C2:
 200k x 20k f32, ~97 % sparse, randomized SVD k=50, p=10, q=4, QR normalizer); the line also
-carries a 3-step `c4_1gpu` record (BASELINE configs[3]'s 1M x 30k matrix on the one GPU: the
-shape north_star's roofline target is quoted on).  For N>1 the default is BASELINE configs[3]
+carries every other BASELINE config on the one GPU as a sub-record: `c3` (configs[2]: masked f64
+Lanczos, 3 steps, roofline per Lanczos step), `c4_1gpu` (configs[3]'s 1M x 30k matrix: the shape
+north_star's roofline target is quoted on, 3 steps) and `c5_1gpu` (configs[4]: 2M x 50k, k=100,
+2 steps, sweep roofline + executed slots per stored entry).  For N>1 the default is BASELINE configs[3]
 STRONG-scaled: the 1M x 30k matrix split by rows over the ranks (`"scaling": "strong"`), rows
 range-partitioned, panels all-reduced over RCCL inside the library; `--scaling weak` gives
 every rank a 200k-row shard of the (N*200k) x 20k matrix instead.
@@ -17,8 +19,9 @@ every rank a 200k-row shard of the (N*200k) x 20k matrix instead.
 One JSON line on rank 0: metric/value = whole-job algorithmic GB/s of fit_transform (SURVEY.md
 §8d formula / wall-clock), ms_per_step = fit_transform wall-clock, `roofline` for the dominant
 kernel (the sparse x dense sweep, HIP-event timed on the library's stream), `cpu_baseline` = the
-C/OpenMP restatement of the reference algorithm timed on a bounded row sample of the same
-workload (rank 0, N=1 only).
+C/OpenMP restatement of the reference algorithm timed on the WHOLE workload on the box's host
+cores (rank 0, N=1 only), `cpu_baseline_reference` = the reference's own crate (baseline/rust_ref)
+where a Rust toolchain with a populated registry exists, else {"available": false, "reason": ...}.
 """
 import argparse
 import json
@@ -51,12 +54,12 @@ def alg_bytes(m, n, nnz, l, k, q, tsize=4):
     return sweep, (2 * q + 2) * sweep + stats + transform
 
 
-def cpu_baseline(name, n, density, k, p, q, seed, gen_device="cpu"):
-    """The oracle's C restatement ("port") on a bounded row sample of the same workload."""
+def cpu_baseline(name, m, n, density, k, p, q, seed, gen_device="cpu", rows=None):
+    """The oracle's C restatement ("port") on the whole workload; `rows` bounds the sample (--cpu-sample-rows)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     from sapca import synth
-    ms = 30000 if name != "small" else 5000
+    ms = m if not rows else min(m, rows)
     try:
         share = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -64,15 +67,48 @@ def cpu_baseline(name, n, density, k, p, q, seed, gen_device="cpu"):
     orc.set_num_threads(min(share, 16))      # a 1-GPU box gives this job 16 host cores
     ptr, idx, val = synth.gapped_csr(ms, n, density, k, seed=seed, dtype=torch.float32, device=gen_device, chunk_elems=1 << 24)
     ptr, idx, val = ptr.cpu().numpy(), idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
+    torch.cuda.empty_cache()
     om = synth.gaussian_panel(n, k + p, 42).numpy().astype(np.float32)
     t0 = time.perf_counter()
     rc, comps, sing, ev, mean, tv = orc.randomized_fit(ptr, idx, val, ms, n, k, p, q, "QR", True, om)
+    t1 = time.perf_counter()
     orc.transform_sparse(ptr, idx, val, ms, n, comps, mean, True)   # closed form of the Q2 loop (the literal loop is O(m*k*nnz))
     dt = time.perf_counter() - t0
     _, total = alg_bytes(ms, n, len(val), k + p, k, q)
+    what = "the whole workload" if ms == m else f"{ms} x {n} row sample of the workload"
     return {"value": total / dt / 1e9, "unit": "GB/s", "cores": orc.num_threads(), "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"{ms} x {n} row sample of the workload ({len(val)} stored entries), fit + closed-form transform, "
+            "ms_per_step": dt * 1e3, "fit_ms": (t1 - t0) * 1e3,
+            "sample": f"{what} ({ms} x {n}, {len(val)} stored entries), one fit + closed-form transform, "
                       f"{dt:.2f} s; restatement of the reference algorithm, not the reference binary"}
+
+
+def reference_binary_baseline(timeout_s=120):
+    """the reference's own crate (baseline/rust_ref: single_algebra =0.9.2, SparsePCABuilder ... fit) timed
+    on this box -- only where `cargo` AND an offline registry holding its dependencies exist.  Runs in a child process that
+    never touches the GPU; otherwise says why not."""
+    import shutil
+    import subprocess
+    cargo = shutil.which("cargo")
+    if cargo is None:
+        return {"available": False, "reason": "reference binary: unavailable on this box (no `cargo` on PATH; no Rust toolchain in the image)"}
+    home = os.environ.get("CARGO_HOME", os.path.expanduser("~/.cargo"))
+    crate = os.path.join(ROOT, "baseline", "rust_ref")
+    if not (os.path.isdir(os.path.join(home, "registry")) or os.path.isdir(os.path.join(crate, "vendor"))):
+        return {"available": False, "reason": f"reference binary: unavailable on this box (cargo at {cargo}, but no populated registry under "
+                                              f"{home}/registry and no vendored crates; there is no network)"}
+    try:
+        env = dict(os.environ, CARGO_NET_OFFLINE="true")
+        b = subprocess.run([cargo, "build", "--release", "--offline"], cwd=crate, env=env, capture_output=True, text=True, timeout=timeout_s)
+        if b.returncode != 0:
+            return {"available": False, "reason": "reference binary: `cargo build --release --offline` failed: " + b.stderr[-300:]}
+        out = {}
+        for cfg in ("c1", "c2"):
+            r = subprocess.run([cargo, "run", "--release", "--offline", "--", cfg], cwd=crate, env=env, capture_output=True, text=True,
+                               timeout=timeout_s)
+            out[cfg] = r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "failed: " + r.stderr[-200:]
+        return {"available": True, "kind": "reference", "cores": os.cpu_count(), "runs": out}
+    except Exception as e:   # never lose the line to the probe
+        return {"available": False, "reason": "reference binary: " + repr(e)}
 
 
 def cpu_model():
@@ -87,46 +123,56 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def bench_lanczos(args, rank, local_rank, world, dev):
-    """configs[2]: MaskedSparsePCA fit_transform, f64, Lanczos on the mask-compacted (uncentred) operator."""
+def run_lanczos(steps, warmup, local_rank, dev):
+    """configs[2]: MaskedSparsePCA fit_transform, f64, Lanczos on the mask-compacted (uncentred) operator: the record."""
     import sapca
     from sapca import synth
-    assert world == 1, "the c3 workload is a 1-GPU configuration"
     m, n, density, k, _, _ = WORKLOADS["c3"]
     ptr, idx, val = synth.gapped_csr(m, n, density, k, seed=42, centred=False, dtype=torch.float64, device=dev)
     mask = synth.bernoulli_mask(n, 0.6, 7).numpy()
     x = sapca.DeviceCsr(ptr, idx, val, (m, n))
     est = (sapca.MaskedSparsePCABuilder.new().n_components(k).mask(mask).device(local_rank).collect_timings(True)
            .svd_method(sapca.SVDMethod.Lanczos()).build())
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = est.fit_transform(x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    lz_ms, steps = 0.0, 0
-    for _ in range(args.steps):
+    lz_ms, lsteps = 0.0, 0
+    stage = {}
+    for _ in range(steps):
         out = est.fit_transform(x)
         t = est.timings()
         lz_ms += t.lanczos_ms
-        steps += int(t.lanczos_steps)
+        lsteps += int(t.lanczos_steps)
+        for f in ("prepare_ms", "stats_ms", "transform_ms", "fit_total_ms"):
+            stage[f] = stage.get(f, 0.0) + getattr(t, f) / steps
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert out.shape == (m, k) and bool(torch.isfinite(out).all())
     n_used = int(mask.sum())
-    nnz_used = int(mask[idx.cpu().numpy()].sum())
+    nnz_used = int(torch.as_tensor(mask, device=dev)[idx.long()].sum().item())
     # SURVEY.md 8d: per Lanczos step 2*[nnz'*(8+4) + (m+1)*8] + (m + 2n')*8 bytes
     step_bytes = 2 * (nnz_used * 12 + (m + 1) * 8) + (m + 2 * n_used) * 8
-    achieved = step_bytes * steps / (lz_ms * 1e-3) / 1e9
-    total_bytes = step_bytes * steps / args.steps + 2 * (val.numel() * 12 + (m + 1) * 8)   # + stats and transform passes
-    print(json.dumps({
-        "metric": "masked_sparse_pca_lanczos_fit_transform_algorithmic_throughput", "value": total_bytes / (dt / args.steps) / 1e9,
-        "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"c3: MaskedSparsePCA {m} x {n} CSR f64 density {density}, 60 % Bernoulli mask seed 7 ({n_used} kept), "
-                               f"SVDMethod::Lanczos k={k} (uncentred operator), inputs resident in HBM",
-                   "nnz": int(val.numel()), "nnz_masked": nnz_used, "lanczos_steps_per_fit": steps / args.steps},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "Lanczos step (SpMV pair + re-orthogonalisation), HIP events on the library stream",
-                     "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": lz_ms / max(steps, 1)}}))
-    assert out.shape == (m, k)
+    achieved = step_bytes * lsteps / (lz_ms * 1e-3) / 1e9
+    total_bytes = step_bytes * lsteps / steps + 2 * (val.numel() * 12 + (m + 1) * 8)   # + stats and transform passes
+    rec = {"metric": "masked_sparse_pca_lanczos_fit_transform_algorithmic_throughput", "value": total_bytes / (dt / steps) / 1e9,
+           "unit": "GB/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "dtype": "f64",
+           "config": {"workload": f"c3: MaskedSparsePCA {m} x {n} CSR f64 density {density}, 60 % Bernoulli mask seed 7 ({n_used} kept), "
+                                  f"SVDMethod::Lanczos k={k} (uncentred operator), inputs resident in HBM",
+                      "nnz": int(val.numel()), "nnz_masked": nnz_used, "lanczos_steps_per_fit": lsteps / steps, "stage_ms": stage},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "Lanczos step (SpMV pair + re-orthogonalisation), HIP events on the library stream",
+                        "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": lz_ms / max(lsteps, 1), "launches_timed": lsteps}}
+    del out, x, ptr, idx, val, est
+    torch.cuda.empty_cache()
+    return rec
+
+
+def bench_lanczos(args, rank, local_rank, world, dev):
+    assert world == 1, "the c3 workload is a 1-GPU configuration"
+    rec = run_lanczos(args.steps, args.warmup, local_rank, dev)
+    rec.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+    print(json.dumps(rec))
 
 
 def free_port():
@@ -316,7 +362,8 @@ def sub_record(r):
     return {"workload": f"{r['workload']}: {r['m_total']} x {r['n']} CSR f32, density {r['density']}, k={r['k']} p={r['p']} q={r['q']} QR, "
                         f"{r['scaling']} scaling, inputs resident in HBM",
             "steps": r["steps"], "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "GB/s", "nnz": int(r["nnz_total"]),
-            "sweep_ms": r["avg_sweep_ms"], "stage_ms": r["stage"], "collectives": r["transport"],
+            "sweep_ms": r["avg_sweep_ms"], "prepare_ms": r["stage"].get("prepare_ms"), "stage_ms": r["stage"], "collectives": r["transport"],
+            "slots_per_stored_entry": (r["slots"] / r["nnz"]) if r["slots"] else None,
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["achieved"] / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": r["sweep_bytes"], "avg_launch_ms": r["avg_sweep_ms"],
                          "launches_timed": len(r["sweep_ms"])}}
@@ -336,6 +383,8 @@ def main():
     ap.add_argument("--weak-c2", action="store_true",
                     help="N > 1: after the strong-scaled C4 headline also run 3 steps of weak-scaled C2 shards (a `weak_c2` record)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0,
+                    help="time the CPU restatement on the first ROWS rows of the workload instead of all of it (C2 whole: about a minute)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measured copy rate, the host-path run, the C1 comparison and the secondary workloads "
                          "(c4_1gpu at one GPU)")
@@ -343,6 +392,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # the reference's own binary, before this process touches a GPU (the probe starts child processes)
+    ref_probe = reference_binary_baseline() if (world == 1 and not args.no_cpu_baseline) else None
     if args.scaling is None:
         # the driver runs `bench.py --gpus N`: N > 1 must measure BASELINE.json configs[3] (1M x 30k split by rows over
         # the ranks: north_star's ">= 6x at 8 GPUs"), one GPU configs[1]
@@ -385,7 +436,15 @@ def main():
     if not args.no_extras:
         try:
             if world == 1 and args.workload == "c2":
-                extra["c4_1gpu"] = sub_record(run_randomized("c4", "strong", 3, 1, rank, world, local_rank, dev, rdev, shared, args.spmm_variant))
+                # every other BASELINE config on this one GPU: configs[2] (masked f64 Lanczos), [3] and [4] (their matrices whole)
+                for key, fn in (("c3", lambda: run_lanczos(3, 1, local_rank, dev)),
+                                ("c4_1gpu", lambda: sub_record(run_randomized("c4", "strong", 3, 1, rank, world, local_rank, dev, rdev, shared, args.spmm_variant))),
+                                ("c5_1gpu", lambda: sub_record(run_randomized("c5", "strong", 2, 1, rank, world, local_rank, dev, rdev, shared, args.spmm_variant)))):
+                    try:
+                        extra[key] = fn()
+                    except Exception as e:
+                        extra[key + "_error"] = repr(e)
+                        torch.cuda.empty_cache()
             elif world > 1 and args.workload == "c4" and args.scaling == "strong" and args.weak_c2:
                 extra["weak_c2"] = sub_record(run_randomized("c2", "weak", 3, 1, rank, world, local_rank, dev, rdev, shared, args.spmm_variant))
         except Exception as e:   # never lose the line to an extra (on every rank the same way: the workload is collective)
@@ -444,7 +503,8 @@ def main():
             line["e2e_host_ms"] = None
             line["e2e_host_error"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, n, density, k, p, q, r["seed"], dev)
+            line["cpu_baseline"] = cpu_baseline(args.workload, m_cfg, n, density, k, p, q, r["seed"], dev, args.cpu_sample_rows)
+            line["cpu_baseline_reference"] = ref_probe
             if not args.no_extras:
                 line["cpu_baseline_c1"] = c1_comparison(dev, local_rank)
         print(json.dumps(line))

@@ -31,10 +31,13 @@ RcclApi& api() {
   static RcclApi a;
   static std::once_flag once;
   std::call_once(once, [] {
+    // (-DSAPCA_DEBUG_SWITCHES builds only: the tests' stand-in for librccl, tests/fake_rccl -- RCCL mode with several ranks on
+    // one GPU.  Opened by its full path and without RTLD_GLOBAL: the process may carry the real RCCL for someone else.)
+    if (const char* fake = dbg_env("SAPCA_RCCL_LIBRARY")) a.so = dlopen(fake, RTLD_NOW | RTLD_LOCAL);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
-      a.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (a.so) break;
+      a.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!a.so) return;
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.so, "ncclGetUniqueId"));
@@ -152,6 +155,7 @@ void Comm::abort() {
   if (mode != RCCL || !api().CommAbort) return;
   // (ncclCommAbort frees the communicator: nobody may touch it again -- the pointers are taken out under the enqueue lock,
   // or without it when the owning thread has been inside an enqueue for 250 ms: that is the hang this call ends)
+  std::lock_guard<std::mutex> state(state_mu);
   std::unique_lock<std::timed_mutex> issue(issue_mu, std::defer_lock);
   (void)issue.try_lock_for(std::chrono::milliseconds(250));
   void* c2 = rccl_comm2.exchange(nullptr);
@@ -165,7 +169,7 @@ int Comm::async_error() {
   if (aborted.load()) return -1;
   if (mode != RCCL || !api().CommGetAsyncError) return 0;
   int e = 0;
-  std::lock_guard<std::timed_mutex> issue(issue_mu);   // (abort() frees the communicators: not while they are being asked)
+  std::lock_guard<std::mutex> state(state_mu);   // (abort() frees the communicators: not while they are being asked)
   void* const c1 = rccl_comm.load();
   void* const c2 = rccl_comm2.load();
   if (aborted.load()) return -1;
@@ -178,6 +182,7 @@ void Comm::destroy() {
   void* c2;
   void* c1;
   {
+    std::lock_guard<std::mutex> state(state_mu);
     std::lock_guard<std::timed_mutex> issue(issue_mu);
     c2 = rccl_comm2.exchange(nullptr);
     c1 = rccl_comm.exchange(nullptr);

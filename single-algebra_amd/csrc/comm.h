@@ -13,15 +13,17 @@ namespace sapca {
 struct Comm {
   uint32_t nranks = 1, rank = 0;
   enum Mode { NONE, RCCL, CALLBACK } mode = NONE;
-  // The communicators are read by the owning thread (allreduce, async_error, destroy) and swapped out by abort() from ANY
-  // thread: atomics, and `issue_mu` is held across an enqueue so that abort() frees a communicator only between two of them
-  // (or after waiting 250 ms for an enqueue that never returns -- the case ncclCommAbort exists for).
+  // The communicators are read by the owning thread (allreduce, destroy), by whoever polls async_error(), and swapped out by
+  // abort() from ANY thread: atomics; `issue_mu` is held across an enqueue so that abort() frees a communicator only between
+  // two of them (or after waiting 250 ms for an enqueue that never returns -- the case ncclCommAbort exists for); `state_mu`
+  // keeps abort() / destroy() and a concurrent async_error() apart (a poll never waits for an enqueue).
   std::atomic<void*> rccl_comm{nullptr};
   // a duplicate of the communicator (ncclCommSplit, all ranks one colour) for collectives issued on a second stream: the
   // first piece's all-reduce of a two-piece A^T sweep runs behind the second piece's sweep (engine.cpp); two streams must
   // not issue on one communicator.  Null when the library has no ncclCommSplit: the sweep then runs in one piece.
   std::atomic<void*> rccl_comm2{nullptr};
   std::timed_mutex issue_mu;
+  std::mutex state_mu;
   std::atomic<bool> aborted{false};   // abort() was called: every later collective fails at once with SAPCA_ERR_COMM
   sapca_allreduce_fn fn = nullptr;
   void* ctx = nullptr;

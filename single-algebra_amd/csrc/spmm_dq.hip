@@ -48,6 +48,13 @@ constexpr int DQ_OFF_UNIT = kOddSteps ? 4 : 8;   // entries per unit of a stream
 static_assert(DQ2_ACC_BASE == 56, "the accumulator operands below are written out for row slots starting at v56");
 
 __host__ __device__ inline int dq_first(int wave, int nquads) { return wave * nquads / DQ_WAVES; }
+// Which of the sixteen streams of a row block a hardware wave walks.  Waves w, w + 4, w + 8, w + 12 share a SIMD, and a
+// block's quads are dealt to the streams s as [s nq / 16, (s + 1) nq / 16): when nq is not a multiple of 16 the longer streams
+// recur with a period that divides 16 (every fourth one for nq = 16 a + 4) -- walked by wave s they would all land on one SIMD
+// (measured, round 5: SIMD 3 carried 8 % more chunks than the others at C2).  Walked in transposed order they spread over
+// the four SIMDs, and the longer ones (s & 3 == 3 first) go to the OLDEST wave of each SIMD, which the issue arbiter serves
+// first (profiles/r05_dq_stamps_c2.txt).
+__host__ __device__ inline int stream_of_wave(int hw_wave) { return (hw_wave & 3) * 4 + 3 - (hw_wave >> 2); }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -56,8 +63,8 @@ typedef unsigned v8u __attribute__((ext_vector_type(8)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // One wave per (row block, tile): lane w < 16 computes the entry offset and chunk count of sweep wave w's stream, and the rank
-// of its step count among the four waves that share its SIMD (waves w, w + 4, w + 8, w + 12: the longest gets 3) -- the
-// sweep's issue priority for that tile.
+// of its step count among the four streams walked on one SIMD (stream_of_wave: streams 4 i .. 4 i + 3; the longest gets 3) --
+// the sweep's issue priority for that tile under DQ2_PRIO.
 __global__ void __launch_bounds__(256)
 dq_info_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __restrict__ chunk_off,
                const uint32_t* __restrict__ wave_off, const uint16_t* __restrict__ steps, uint32_t* __restrict__ info, int64_t nchunks) {
@@ -74,8 +81,8 @@ dq_info_kernel(const int32_t* __restrict__ blk_row0, int nct, const int64_t* __r
       for (int j = 0; j < my_quads; ++j) n += (int)steps[cidx * DQ_BLOCK_QUADS + quad0 + j];
     int rank = 0;
 #pragma unroll
-    for (int d = 4; d < 16; d += 4) {
-      const int other = (wave + d) & 15;
+    for (int d = 1; d < 4; ++d) {   // (streams 4 i .. 4 i + 3 are walked by the hardware waves i, i + 4, i + 8, i + 12: one SIMD)
+      const int other = (wave & 12) | ((wave + d) & 3);
       const int no = __shfl(n, other);
       rank += (no < n || (no == n && other < wave)) ? 1 : 0;
     }
@@ -101,7 +108,7 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
+  const int wave = stream_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)), lane = threadIdx.x & (WAVE - 1);   // (the stream this wave walks)
   const int g = lane / 16, q = lane % 16;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;
@@ -168,7 +175,7 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
   const v8f acc2[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
 #ifdef DQ2_STAMPS
   if (stamps && (int)blockIdx.x < stamp_wgs) {   // [workgroup][wave][12 records][64 tiles]
-    uint32_t* w = stamps + (((size_t)blockIdx.x * DQ_WAVES + wave) * 12) * WAVE + lane;
+    uint32_t* w = stamps + (((size_t)blockIdx.x * DQ_WAVES + threadIdx.x / WAVE) * 12) * WAVE + lane;   // (by hardware wave)
 #pragma unroll
     for (int j = 0; j < 8; ++j) w[j * WAVE] = st8[j];
 #pragma unroll
@@ -224,7 +231,7 @@ spmm_dq_f64_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restr
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x & (WAVE - 1);
+  const int wave = stream_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)), lane = threadIdx.x & (WAVE - 1);   // (the stream this wave walks)
   const int g = lane / 16, q = lane % 16;
   const int row0 = blk_row0[rb], nrows = blk_row0[rb + 1] - row0;
   const int nquads = (nrows + 3) / 4;

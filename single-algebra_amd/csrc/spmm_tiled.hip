@@ -1500,12 +1500,13 @@ constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave o
 
 // With `bnd` (the gather fill below, natural row order of A^T): A^T's row blocks are contiguous column ranges -- block b
 // holds the columns c with (int)((float)c * blk_scale) == b -- and bnd[t * tc + i][b] becomes the position in A's arrays of the first entry of row
-// t + i * nct whose column lies in block b or behind (b = 0..nrb; the row's end for the blocks it does not reach).  A row is
+// t + i * nct whose column lies in block b or behind (b = 0..nrb; the row's end for the blocks it does not reach), counted
+// from the row's first entry (uint32: half the table of round 4's absolute int64 positions, and no memset of it).  A row is
 // sorted by column, so these are the places where the block of the column changes: found in the registers that hold the
 // row's indices for the histogram anyway.
 __global__ void __launch_bounds__(ATD_HIST_THREADS_WIDE)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
-                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, int64_t* __restrict__ bnd, int64_t* __restrict__ disorder) {
+                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, uint32_t* __restrict__ bnd, int64_t* __restrict__ disorder) {
   // disorder: set when a row's entries leave the order the run ends rely on (a block after a later block: the caller handed
   // over rows whose columns do not ascend) -- the host then takes the bucket route, which maps every column through a table
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
@@ -1519,12 +1520,18 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
   int64_t r = (int64_t)t + (int64_t)wave * nct;
   int64_t e0 = (wave < tc && r < m) ? ptr[r] : 0, e1 = (wave < tc && r < m) ? ptr[r + 1] : 0;
   for (int i = wave; i < tc; i += nwaves) {
-    if (r >= m) break;
+    if (r >= m) {   // tile rows past the last row of A: empty runs (the table is not cleared beforehand)
+      if (bnd)
+        for (int j = lane; j <= nrb; j += WAVE) bnd[((int64_t)t * tc + i) * (nrb + 1) + j] = 0u;
+      continue;     // (r only grows: every later row of this wave is past the end too)
+    }
     const int64_t rn = r + (int64_t)nwaves * nct;
     const bool more = i + nwaves < tc && rn < m;
     const int64_t n0 = more ? ptr[rn] : 0, n1 = more ? ptr[rn + 1] : 0;
     int lastb = -1;   // block of the last entry seen in this row (wave-uniform)
-    int64_t* __restrict__ bnd_row = bnd ? bnd + ((int64_t)t * tc + i) * (nrb + 1) : nullptr;   // a row's run ends side by side
+    // a row's run ends side by side, as offsets from the row's first entry (32 bits: a row of A holds fewer than 2^32 entries)
+    uint32_t* __restrict__ bnd_row = bnd ? bnd + ((int64_t)t * tc + i) * (nrb + 1) : nullptr;
+    const int64_t row_e0 = e0;
     for (int64_t base = e0; base < e1; base += 8 * WAVE) {   // eight loads in flight per lane (a wave-uniform trip count: the
       const int64_t eb = base + lane;                         //  boundary search below talks across lanes)
       int c[8];
@@ -1542,7 +1549,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
           const int up = __builtin_amdgcn_update_dpp(0, b, 0x138, 0xf, 0xf, false);   // wave_shr:1 -- lane l reads lane l - 1
           const int prev = lane == 0 ? lastb : up;
           if (valid && b != prev)
-            for (int j = prev + 1; j <= b; ++j) bnd_row[j] = eb + u * WAVE;
+            for (int j = prev + 1; j <= b; ++j) bnd_row[j] = (uint32_t)(eb + u * WAVE - row_e0);
           if (valid && b < prev) *disorder = 1;   // (rare, benign race: every writer stores the same value)
           lastb = __builtin_amdgcn_readlane(b, __builtin_popcountll(valids) - 1);
         }
@@ -1552,7 +1559,7 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
         if (c[u] >= 0) atomicAdd(&atd_h32[c[u] >> 1], 1u << (16 * (c[u] & 1)));   // (at most 320 rows per tile: no carry into the neighbour)
     }
     if (bnd)
-      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd_row[j] = e1;
+      for (int j = lastb + 1 + lane; j <= nrb; j += WAVE) bnd_row[j] = (uint32_t)(e1 - row_e0);
     r = rn;
     e0 = n0;
     e1 = n1;
@@ -1675,7 +1682,8 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
                 const uint32_t* __restrict__ perm, int nct, int ldp_bytes, const int64_t* __restrict__ chunk_off,
                 const uint32_t* __restrict__ quad_off, const uint16_t* __restrict__ steps, Ent* __restrict__ ent,
                 double* __restrict__ psum, double* __restrict__ psq, int64_t n,
-                const int32_t* __restrict__ a_idx, const float* __restrict__ a_val, const int64_t* __restrict__ bnd, int tc, int nrb_all) {
+                const int32_t* __restrict__ a_idx, const float* __restrict__ a_val, const uint32_t* __restrict__ bnd,
+                const int64_t* __restrict__ a_ptr, int64_t a_rows, int tc, int nrb_all) {
   // one pool: the rows' bit masks (40 KiB) and the image the chunk is assembled in (32 KiB); once the ranks are known the
   // masks are dead and the image takes the whole pool (chunks whose entries the threads hold in registers)
   constexpr int MASK_WORDS_ALL = QBLOCK_ROWS * ATD_MASK_WORDS;
@@ -1721,9 +1729,11 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
     if (threadIdx.x < 32 * ATD_MASK_WORDS) {   // (the same first waves; tc <= 320)
       const int i = threadIdx.x, lane = i & (WAVE - 1);
       // (bnd[row][block]: the chunks of one tile, run back to back on this XCD, read neighbouring words of the same lines)
-      const int64_t* br = bnd + ((int64_t)t * tc + i) * (nrb_all + 1) + rb;
-      const int64_t lo = i < tc ? br[0] : 0;
-      const int64_t hi = i < tc ? br[1] : 0;
+      const uint32_t* br = bnd + ((int64_t)t * tc + i) * (nrb_all + 1) + rb;
+      const int64_t arow = (int64_t)t + (int64_t)i * nct;                 // the row of A behind tile row i
+      const int64_t e0 = (i < tc && arow < a_rows) ? a_ptr[arow] : 0;
+      const int64_t lo = i < tc ? e0 + br[0] : 0;
+      const int64_t hi = i < tc ? e0 + br[1] : 0;
       run_lo[i] = lo;
       uint32_t inc = hi > lo ? (uint32_t)(hi - lo) : 0u;
 #pragma unroll
@@ -1952,7 +1962,7 @@ struct AtDirectSrc {
   int64_t n2;
   DevBuf* scratch;         // buckets, bucket offsets, column map, partial sums
   double* stats;           // out: sum | sumsq per column of A (may be null)
-  const int64_t* bnd;      // gather fill: ends of every (A^T row block, A row) run for `nrb_nat` natural blocks (or null)
+  const uint32_t* bnd;     // gather fill: ends of every (A^T row block, A row) run for `nrb_nat` natural blocks (or null)
   int64_t nrb_nat;
   const std::vector<int32_t>* blk_nat;   // ... and where those blocks start (float_blocks below)
 };
@@ -2300,7 +2310,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
       // natural blocks are column ranges of A: every chunk reads its runs of A's rows itself (no buckets, no scatter pass)
       hipLaunchKernelGGL(atd_fill_kernel<true>, dim3((unsigned)(8 * ((nct + 7) / 8) * nrb)), dim3(ATD_THREADS), 0, s, (const uint2*)nullptr,
                          (const int64_t*)nullptr, d_blk, d_perm, nct, ldp * 4, d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent,
-                         d_psum, d_psq, op_rows, A.idx, A.val, direct->bnd, tc, (int)nrb);
+                         d_psum, d_psq, op_rows, A.idx, A.val, direct->bnd, A.ptr, A.rows, tc, (int)nrb);
     } else {
       hipLaunchKernelGGL(atd_colmap_kernel, dim3((unsigned)((op_rows + 255) / 256)), dim3(256), 0, s, d_blk, (int)nrb, d_perm, op_rows,
                          d_colmap);
@@ -2310,7 +2320,7 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
                          A.idx, A.val, A.rows, nct, tc, d_colmap, d_raw, d_cursor, d_bucket);
       hipLaunchKernelGGL(atd_fill_kernel<false>, dim3((unsigned)nchunks), dim3(ATD_THREADS), 0, s, d_bucket, d_raw, d_blk, d_perm, nct, ldp * 4,
                          d_chunk, d_quad_off, reinterpret_cast<const uint16_t*>(d_steps), d_ent, d_psum, d_psq, op_rows,
-                         (const int32_t*)nullptr, (const float*)nullptr, (const int64_t*)nullptr, tc, (int)nrb);
+                         (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int64_t*)nullptr, (int64_t)0, tc, (int)nrb);
     }
     if (direct->stats)
       hipLaunchKernelGGL(atd_stats_reduce_kernel, dim3((unsigned)((op_rows + 63) / 64)), dim3(1024), 0, s, d_psum, d_psq, op_rows, nct,
@@ -2394,18 +2404,16 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   int64_t nrb_nat = 0;
   int nsplit_nat = 1;
   natural_partition(n, nct, dq_block_rows(n), nrb_nat, nsplit_nat);
-  int64_t* bnd = nullptr;
+  uint32_t* bnd = nullptr;
   if (dbg_env("SAPCA_AT_BUCKETS") == nullptr && nrb_nat <= 4096) {
-    const size_t bytes = (size_t)(nrb_nat + 1) * (size_t)nct * tc * sizeof(int64_t);
-    // (8 (nrb + 1) bytes per row of A: 264 MB at C4, gigabytes at 10M rows -- a table that cannot be allocated is not a failed
-    //  fit: the bucket route needs none)
+    // (4 (nrb + 1) bytes per row of A: 132 MB at C4 -- round 4: 264 MB of int64, cleared before every fit; the histogram pass
+    //  now writes every word itself.  A table that cannot be allocated is not a failed fit: the bucket route needs none)
     try {
-      bnd = buf.bounds.as<int64_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
+      bnd = buf.bounds.as<uint32_t>((size_t)(nrb_nat + 1) * (size_t)nct * tc);
     } catch (const Error&) {
       (void)hipGetLastError();
       bnd = nullptr;
     }
-    if (bnd) SAPCA_HIP(hipMemsetAsync(bnd, 0, bytes, s));   // (tile rows past the last row of A: empty runs)
   }
   const size_t hist_lds = (size_t)n2 * 2;
   static LdsAttrState hist_attr;

@@ -6,7 +6,8 @@
 // and the A/B scripts under tools/ load that variant through SAPCA_LIB_PATH.
 //
 // What a release build does read, as plain getenv calls at their two sites:
-//   SAPCA_AT_OVERLAP=0      engine.cpp   the A^T sweep of a multi-rank fit in one piece (no collective on a side stream)
+//   SAPCA_AT_OVERLAP=0|1    engine.cpp   0: the A^T sweep of a multi-rank fit in one piece (no collective on a side stream);
+//                                        1: in two pieces under RCCL too (opt-in there until it has run on more than one GPU)
 //   SAPCA_MULTI_INPROCESS=1 multi.cpp    sapca_multi_* members talk through page-locked host memory instead of RCCL
 //
 // The switches of the debug variant (name: effect), by file:
@@ -20,7 +21,8 @@
 //   dense.hip    SAPCA_CHOL_GENERAL, SAPCA_EIG_DEVICE
 //   lanczos.hip  SAPCA_SPMV_NO_LDS, SAPCA_SPMV_NO_SLICE_GRID, SAPCA_SPMV_IDX32, SAPCA_LANCZOS_CHECK
 //   api.cpp      SAPCA_UPLOAD_NARROW_ON_DEVICE, SAPCA_UPLOAD_STATS_OFF
-//   comm.cpp     SAPCA_COMM_FORCE_RCCL (a one-rank RCCL communicator: how a one-GPU box tests the binding), SAPCA_COMM_NO_SPLIT
+//   comm.cpp     SAPCA_COMM_FORCE_RCCL (a one-rank RCCL communicator: how a one-GPU box tests the binding), SAPCA_COMM_NO_SPLIT,
+//                SAPCA_RCCL_LIBRARY (path of the tests' stand-in for librccl: tests/fake_rccl)
 #pragma once
 #include <cstdlib>
 

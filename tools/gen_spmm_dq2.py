@@ -48,6 +48,19 @@ VCNT, VCNT2 = 48, 49   # two-step groups - 1 of this wave's quads in the current
 DEPTH = int(os.environ.get("DQ2_DEPTH", "2"))   # two-step groups in flight per wave (3: a third register set behind the accumulators)
 ODD = os.environ.get("DQ2_ODD", "1") != "0"     # quads of any step count (the format does not round a quad's steps up to even: the default since round 4): the counter runs per step; DQ2_ODD=0 + -DSAPCA_EVEN_STEPS: rounds 2-3
 PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from the info table
+# Issue priority per chunk (round 5; profiles/r05_dq_stamps_*.txt).  A SIMD issues oldest-wave-first among equal priorities: the
+# four waves of a SIMD drift apart by +-20 % per tile and the oldest waits a fifth of its time at the tile barrier while the
+# youngest, alone at the end, cannot fill the SIMD.  1: the priority rotates, (position of the wave among its SIMD's four + chunks
+# started) mod 4; 2: by the chunks the wave still has in this tile (most remaining first), min(3, remaining >> DQ2_ROT_SHIFT).
+# One counter check per POSITION (two steps) instead of one per step: `s_sub 2` borrows exactly when the quad ends inside the
+# position (1 or 2 steps left), and that case runs out of line (end_s_k: once per quad and tile).  The straight path of a position
+# is 13 instructions instead of 15, with one conditional branch instead of two.
+ONEBR = os.environ.get("DQ2_ONEBR", "0") != "0"
+ROT = int(os.environ.get("DQ2_ROT", "0"))
+ROT_SHIFT = int(os.environ.get("DQ2_ROT_SHIFT", "1"))
+ROT_SUB = int(os.environ.get("DQ2_ROT_SUB", "0"))     # 2: min(3, max(0, remaining - SUB) >> SHIFT)
+ROT_AGE = os.environ.get("DQ2_ROT_AGE", "0") != "0"   # 2: the wave's place among its SIMD's four (0 = oldest) is added to `remaining`, and is
+                                                      # its priority between the tile barrier and its first chunk (the youngest leaves the barrier last)
 ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved with the next group's DPP instructions, reads last
 # experiment switches (environment, read when the header is generated)
 B64 = os.environ.get("DQ2_B64", "0") != "0"     # one 64-bit row_newbcast move per step ({offset, value}) + a plain add, instead of add_dpp + mov_dpp
@@ -124,6 +137,7 @@ S_CTL = 86                    # s[86:87] chunk routine of the next chunk's entry
 S_CTLA = [88, 90, 92]         # s[88:93] the three chunk routines
 S_BODY0 = 94                  # s[94:95] position 0 of slot 0's copy
 S_QM = 96                     # s[96:97] lanes that hold one of this wave's quads
+S_ROT = 83                    # DQ2_ROT=1: chunks started + the wave's place among the four of its SIMD
 
 _uid = [0]
 
@@ -154,6 +168,13 @@ def stamp_pairs_clear(L):
         L.append(f"s_mov_b64 s[{pr}:{pr + 1}], 0")
     for a in (ST_SVM, ST_SL, ST_SOWN, ST_SP4):
         L.append(f"s_mov_b32 s{a}, 0")
+
+
+def setprio_tree(L, sreg, tag):
+    """s_setprio takes an immediate: s[sreg] in 0..3 through a two-level branch"""
+    L += [f"s_cmp_lt_u32 s{sreg}, 2", f"s_cbranch_scc1 rotlo_{tag}", f"s_cmp_eq_u32 s{sreg}, 2", f"s_cbranch_scc1 rot2_{tag}", "s_setprio 3",
+          f"s_branch rotdone_{tag}", f"rot2_{tag}:", "s_setprio 2", f"s_branch rotdone_{tag}", f"rotlo_{tag}:", f"s_cmp_eq_u32 s{sreg}, 0",
+          f"s_cbranch_scc1 rot0_{tag}", "s_setprio 1", f"s_branch rotdone_{tag}", f"rot0_{tag}:", "s_setprio 0", f"rotdone_{tag}:"]
 
 
 def grp_a_parts(k):
@@ -297,6 +318,7 @@ def bodies(L):
     """RG copies of a chunk's eight two-step groups.  Position k of slot s: the FMAs of group k into slot s's accumulators,
     then group k + 2 issued; the quad's counter; fall through to position k + 1 (position 7: the chunk routine).
     ODD: the counter runs per step, so a quad may hand over between the two steps of a group (body_s_k_mid)."""
+    tails = []
     for s in range(RG):
         for k in range(8):
             L.append(f"body_{s}_{k}:")
@@ -307,6 +329,22 @@ def bodies(L):
             if STAMPS and k in (0, 4):
                 L.append(f"s_memtime s[{ST_B if k == 0 else ST_D4}:{(ST_B if k == 0 else ST_D4) + 1}]")
             f0, f1 = grp_fma_parts(s, k)
+            if ODD and ONEBR:
+                # S_C = steps the quad has left, this position's first included, minus one
+                L += [f"s_sub_u32 s{S_C}, s{S_C}, 2", f"s_cbranch_scc1 end_{s}_{k}"]
+                L += f0
+                L.append(f"body_{s}_{k}_mid:")
+                L += f1
+                nxt = []
+                if k + DEPTH < 8:
+                    grp_a(k + DEPTH, nxt)
+                L += nxt
+                # out of line: the quad ends inside this position
+                T = [f"end_{s}_{k}:", f"s_cmp_eq_u32 s{S_C}, -1", f"s_cbranch_scc1 end2_{s}_{k}"]
+                T += f0 + [f"s_branch landm_{s + 1}_{k}"]                      # one step left: the second step is the next quad's first
+                T += [f"end2_{s}_{k}:"] + f0 + [f"end2_{s}_{k}_mid:"] + f1 + nxt + [f"s_branch land_{s + 1}_{k}"]   # two left
+                tails.append(T)
+                continue
             if ODD:
                 L += f0
                 L += [f"s_sub_u32 s{S_C}, s{S_C}, 1", f"s_cbranch_scc1 landm_{s + 1}_{k}", f"body_{s}_{k}_mid:"]
@@ -324,6 +362,8 @@ def bodies(L):
             L.append(f"s_sub_u32 s{S_C}, s{S_C}, 1")
             L.append(f"s_cbranch_scc1 land_{s + 1}_{k}")          # the quad's last group: on to the next non-empty quad
         L.append(f"s_setpc_b64 s[{S_CTL}:{S_CTL + 1}]")
+    for T in tails:
+        L += T
 
 
 def stubs(L):
@@ -350,6 +390,8 @@ def stubs(L):
                     continue
                 L += [f"v_readlane_b32 s{S_C}, v{VCNT}, {s}", f"s_cmp_lt_i32 s{S_C}, 0", f"s_cbranch_scc1 landm_{s + 1}_{k}"]
                 set_ret(L, s)
+                if ONEBR:   # the quad's first step is the position's second: one step fewer at the next position -- or none at all
+                    L += [f"s_sub_u32 s{S_C}, s{S_C}, 1", f"s_cbranch_scc1 end2_{s}_{k}_mid"]
                 L.append(f"s_branch body_{s}_{k}_mid")
     # tile entry: the first non-empty quad, then the first chunk's routine
     L.append("enter_0:")
@@ -384,6 +426,19 @@ def chunk_routines(L, pattern):
             # pattern mode (MaskedSparsePCA's projection, quirk Q3): every stored non-zero value counts as 1, zeros
             # (padding, and stored zeros, which the caller handles) as 0
             L += ["s_nop 0", f"v_cmp_neq_f32 vcc, 0, v{ECUR[1]}", f"v_cndmask_b32 v{ECUR[1]}, 0, 1.0, vcc"]
+        if ROT:
+            if ROT == 1:
+                L += [f"s_add_u32 s{S_ROT}, s{S_ROT}, 1", f"s_and_b32 s{S_E}, s{S_ROT}, 3"]
+            else:
+                L.append(f"s_mov_b32 s{S_E}, s{S_REM}")
+                if ROT_AGE:
+                    L.append(f"s_add_u32 s{S_E}, s{S_E}, s{S_ROT}")
+                if ROT_SUB:
+                    L += [f"s_max_u32 s{S_E}, s{S_E}, {ROT_SUB}", f"s_sub_u32 s{S_E}, s{S_E}, {ROT_SUB}"]
+                if ROT_SHIFT:
+                    L.append(f"s_lshr_b32 s{S_E}, s{S_E}, {ROT_SHIFT}")
+                L.append(f"s_min_u32 s{S_E}, s{S_E}, 3")
+            setprio_tree(L, S_E, f"c{r}")
         # one LDS-DMA piece of the next tile while there are any (out of line)
         L += [f"s_cmp_lg_u32 s{S_NP}, 0", f"s_cbranch_scc1 dma_{r}", f"dmaback_{r}:"]
         # the buffer's next load: three chunks ahead in this tile; in the last three slots the next tile's first chunks (linked)
@@ -434,6 +489,12 @@ def body(pattern):
     L += [f"s_lshl_b32 s{S_A}, %[myq], 1", f"v_cmp_gt_u32 vcc, s{S_A}, %[l2]", f"s_mov_b64 s[{S_QM}:{S_QM + 1}], vcc"]
     L += [f"v_readfirstlane_b32 s{S_ROWBW}, %[rowb0]", f"s_mul_i32 s{S_PSTEP}, s{S_4NCT}, %[stride]",
           f"s_mul_i32 s{S_LIM}, %[nct], {RPP - 1}", f"s_add_u32 s{S_LIM}, s{S_LIM}, s{S_ROWBW}", f"s_sub_u32 s{S_LIM}, %[prm1], s{S_LIM}"]
+    if ROT == 1 or (ROT and ROT_AGE):
+        # the stream slot this wave walks is (wdma - LDS base) / 5120; hardware wave w walks slot (w & 3) * 4 + 3 - w / 4
+        # (spmm_dq.hip, stream_of_wave), so 3 - (slot & 3) = w / 4 is the wave's place among the four of its SIMD (0: the oldest)
+        L += [f"v_readfirstlane_b32 s{S_ROT}, %[lb]", f"s_sub_u32 s{S_ROT}, %[wdma], s{S_ROT}", f"s_lshr_b32 s{S_ROT}, s{S_ROT}, 10",
+              f"s_mul_i32 s{S_ROT}, s{S_ROT}, 205", f"s_lshr_b32 s{S_ROT}, s{S_ROT}, 10", f"s_and_b32 s{S_ROT}, s{S_ROT}, 3",
+              f"s_sub_u32 s{S_ROT}, 3, s{S_ROT}"]
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
     # first tile: this wave's five pieces into buffer 0, synchronously
@@ -475,6 +536,8 @@ def body(pattern):
     wait_vmcnt(L, S_ND, 6)
     stamp(L, ST_R + 2)
     L += ["s_barrier"]
+    if ROT == 2 and ROT_AGE:
+        setprio_tree(L, S_ROT, "bar")
     stamp(L, ST_R + 3)
     # the step counts (issued before the last three entry loads of a linked predecessor); everything of a tile that loaded its own
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 cnt_pre", "s_waitcnt vmcnt(0)", "s_branch cnt_ok", "cnt_pre:", "s_waitcnt vmcnt(3)", "cnt_ok:"]
@@ -551,7 +614,7 @@ def clobbers():
 
 
 def main():
-    global RG, STAMPS
+    global RG, STAMPS, B64, FMAC, ILV, DEPTH
     here = os.path.dirname(os.path.abspath(__file__))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "single-algebra_amd", "csrc", "spmm_dq2_gen.h")
     with open(path, "w") as out:
@@ -572,21 +635,22 @@ def main():
                 out.write("\n")
                 print(f"wrote {name}: {len(L)} lines")
             out.write(f"#define DQ2_MAIN_CLOBBERS_{rg} " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
-        # the f64 sweep: four row slots per lane group (blocks of <= 256 rows, the f64 quad format's), accumulators from v80
-        if not (B64 or FMAC or ILV or DEPTH != 2):
-            stamps_f32, STAMPS = STAMPS, False   # (the f64 sweep carries no stamps)
-            RG = 4
-            set_f64(True)
-            _uid[0] = 0
-            L = uniq_labels(body(False))
-            out.write("#define DQ2_F64_ACC_BASE 80\n#define DQ2_MAIN_ASM_F64 \\\n")
-            for ln in L:
-                out.write(f'  "{ln}\\n" \\\n')
-            out.write("\n")
-            out.write("#define DQ2_MAIN_CLOBBERS_F64 " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
-            print(f"wrote DQ2_MAIN_ASM_F64: {len(L)} lines")
-            set_f64(False)
-            STAMPS = stamps_f32
+        # the f64 sweep: four row slots per lane group (blocks of <= 256 rows, the f64 quad format's), accumulators from v80;
+        # the f32 experiment switches (B64, FMAC, ILV, DEPTH, stamps) do not apply to it
+        keep = (STAMPS, B64, FMAC, ILV, DEPTH)
+        STAMPS, B64, FMAC, ILV, DEPTH = False, False, False, False, 2
+        RG = 4
+        set_f64(True)
+        _uid[0] = 0
+        L = uniq_labels(body(False))
+        out.write("#define DQ2_F64_ACC_BASE 80\n#define DQ2_MAIN_ASM_F64 \\\n")
+        for ln in L:
+            out.write(f'  "{ln}\\n" \\\n')
+        out.write("\n")
+        out.write("#define DQ2_MAIN_CLOBBERS_F64 " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+        print(f"wrote DQ2_MAIN_ASM_F64: {len(L)} lines")
+        set_f64(False)
+        STAMPS, B64, FMAC, ILV, DEPTH = keep
 
 
 if __name__ == "__main__":
