@@ -27,6 +27,19 @@
  *   - inputs are borrowed for the duration of a call; outputs are written into
  *     caller-allocated buffers.
  *   - a handle is not thread-safe; distinct handles may be used concurrently.
+ *
+ * Deviations from the reference (everything else, quirks included, is the reference's behaviour):
+ *   1. a fit whose SVD returns fewer than k values gives SAPCA_ERR_SVD where the reference panics on s[i]
+ *      (sparse/mod.rs:213-215);
+ *   2. mean_ has n_cols zeros when center = false (the reference: n_samples zeros, never read, sparse/mod.rs:116);
+ *   3. no unconditional stdout (the reference prints from MaskedSparsePCA::fit, sparse_masked/mod.rs:373-378);
+ *   4. n_components + n_oversamples is limited to 1024 (tuned to 128);
+ *   5. SVDMethod::Lanczos: svd_las2 of single-svdlib is SVDLIBC's las2, a single-vector Lanczos with SELECTIVE
+ *      re-orthogonalisation; csrc/lanczos.hip keeps the recurrence, the end interval [-1e-30, 1e30], kappa and the iteration
+ *      cap of the call sites (sparse/mod.rs:135-143, sparse_masked/mod.rs:316-331) but re-orthogonalises every new vector
+ *      against all previous ones (two passes of classical Gram-Schmidt on the device: one GEMV pair instead of las2's
+ *      bookkeeping of which Ritz vectors have converged).  Converged triplets agree to kappa; the number of Lanczos steps
+ *      taken, and triplets that have NOT converged at the cap, can differ.
  */
 #ifndef SAPCA_H
 #define SAPCA_H

@@ -15,6 +15,11 @@
 //! `sapca::` (the module tree `dimred::pca::{sparse, sparse_masked}` is mirrored below).
 //!
 //! UNTESTED SOURCE: written against include/sapca.h, never compiled (no rustc in the build image).
+// `CsrMatrix::row_offsets()` / `col_indices()` are `&[usize]` and cross the FFI as `*const u64` (include/sapca.h takes the
+// reference's index arrays zero-copy): only sound where usize IS 64 bits wide.
+#[cfg(not(target_pointer_width = "64"))]
+compile_error!("sapca passes nalgebra_sparse's usize index arrays to libsapca as u64: 64-bit targets only");
+
 use anyhow::{anyhow, Result};
 use nalgebra_sparse::CsrMatrix;
 use ndarray::{Array1, Array2};

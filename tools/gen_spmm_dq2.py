@@ -55,12 +55,15 @@ PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from t
 # One counter check per POSITION (two steps) instead of one per step: `s_sub 2` borrows exactly when the quad ends inside the
 # position (1 or 2 steps left), and that case runs out of line (end_s_k: once per quad and tile).  The straight path of a position
 # is 13 instructions instead of 15, with one conditional branch instead of two.
-ONEBR = os.environ.get("DQ2_ONEBR", "0") != "0"
-ROT = int(os.environ.get("DQ2_ROT", "0"))
+ONEBR = os.environ.get("DQ2_ONEBR", "1") != "0"   # (the default since round 5; DQ2_ONEBR=0: a check per step)
+ROT = int(os.environ.get("DQ2_ROT", "2"))        # (the default since round 5: 2; DQ2_ROT=0: none)
 ROT_SHIFT = int(os.environ.get("DQ2_ROT_SHIFT", "1"))
 ROT_SUB = int(os.environ.get("DQ2_ROT_SUB", "0"))     # 2: min(3, max(0, remaining - SUB) >> SHIFT)
 ROT_AGE = os.environ.get("DQ2_ROT_AGE", "0") != "0"   # 2: the wave's place among its SIMD's four (0 = oldest) is added to `remaining`, and is
                                                       # its priority between the tile barrier and its first chunk (the youngest leaves the barrier last)
+# 3: most-remaining-first only where it decides who reaches the barrier last -- the last three chunks of a (wave, tile) stream
+# run at priority 2, 1, 0 and everything before at 3; set on the out-of-line path those chunks take anyway (tail_r), so the
+# straight path of a chunk carries no priority code at all.  DQ2_ROT_AGE=1: the two younger waves of a SIMD step down one chunk later.
 ILV = os.environ.get("DQ2_ILV", "0") != "0"     # FMAs of a group interleaved with the next group's DPP instructions, reads last
 # experiment switches (environment, read when the header is generated)
 B64 = os.environ.get("DQ2_B64", "0") != "0"     # one 64-bit row_newbcast move per step ({offset, value}) + a plain add, instead of add_dpp + mov_dpp
@@ -459,7 +462,16 @@ def chunk_routines(L, pattern):
         L.append(f"s_branch dmaback_{r}")
         # last three slots of a tile: chunk 3 - rem of the next tile when linked (its step counts go first, rem == 3);
         # otherwise a load nobody reads, so that the slot still issues one (the wait counts rely on it)
-        L += [f"tail_{r}:", f"s_cmp_eq_u32 s{S_LINK}, 0", f"s_cbranch_scc1 dummy_{r}",
+        L.append(f"tail_{r}:")
+        if ROT == 3:
+            src = S_REM
+            if ROT_AGE:   # S_ROT = 1 for the two younger waves of the SIMD
+                L += [f"s_add_u32 s{S_E}, s{S_REM}, s{S_ROT}"]
+                src = S_E
+            L += [f"s_cmp_ge_u32 s{src}, 4", f"s_cbranch_scc1 tp3_{r}", f"s_cmp_eq_u32 s{src}, 3", f"s_cbranch_scc1 tp2_{r}", f"s_cmp_eq_u32 s{src}, 2",
+                  f"s_cbranch_scc1 tp1_{r}", "s_setprio 0", f"s_branch tpd_{r}", f"tp1_{r}:", "s_setprio 1", f"s_branch tpd_{r}", f"tp2_{r}:", "s_setprio 2",
+                  f"s_branch tpd_{r}", f"tp3_{r}:", "s_setprio 3", f"tpd_{r}:"]
+        L += [f"s_cmp_eq_u32 s{S_LINK}, 0", f"s_cbranch_scc1 dummy_{r}",
               f"s_cmp_lg_u32 s{S_REM}, 3", f"s_cbranch_scc1 nocnt_{r}",
               f"global_load_ushort v{VCNT2}, %[l2c], s[{S_STP}:{S_STP + 1}] offset:512",
               f"s_add_u32 s{S_ND}, s{S_ND}, 1", f"nocnt_{r}:",
@@ -495,6 +507,8 @@ def body(pattern):
         L += [f"v_readfirstlane_b32 s{S_ROT}, %[lb]", f"s_sub_u32 s{S_ROT}, %[wdma], s{S_ROT}", f"s_lshr_b32 s{S_ROT}, s{S_ROT}, 10",
               f"s_mul_i32 s{S_ROT}, s{S_ROT}, 205", f"s_lshr_b32 s{S_ROT}, s{S_ROT}, 10", f"s_and_b32 s{S_ROT}, s{S_ROT}, 3",
               f"s_sub_u32 s{S_ROT}, 3, s{S_ROT}"]
+        if ROT == 3:
+            L.append(f"s_lshr_b32 s{S_ROT}, s{S_ROT}, 1")
     # info window: lane t' holds {entry offset / 8, chunk count} of tile t0 + 64 * window + t'
     L += [f"global_load_dwordx2 v[{VINFO[0]}:{VINFO[1]}], %[l8], s[{S_INFO}:{S_INFO + 1}]"]
     # first tile: this wave's five pieces into buffer 0, synchronously
@@ -538,6 +552,8 @@ def body(pattern):
     L += ["s_barrier"]
     if ROT == 2 and ROT_AGE:
         setprio_tree(L, S_ROT, "bar")
+    if ROT == 3:
+        L.append("s_setprio 3")
     stamp(L, ST_R + 3)
     # the step counts (issued before the last three entry loads of a linked predecessor); everything of a tile that loaded its own
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 cnt_pre", "s_waitcnt vmcnt(0)", "s_branch cnt_ok", "cnt_pre:", "s_waitcnt vmcnt(3)", "cnt_ok:"]
