@@ -175,6 +175,47 @@ def bench_lanczos(args, rank, local_rank, world, dev):
     print(json.dumps(rec))
 
 
+def measure_traffic(workload, n_sweeps, timeout_s=150):
+    """HBM-side bytes of one sweep, measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a
+    pass) over one step of the same workload, each a child process (`rocprofv3 ... -- python3 bench.py --steps 1 --no-extras`);
+    the sweep kernels' counters are summed over the step and divided by its sweeps.  Units and gfx950 corrections as
+    MI355X_MICROARCH.md prescribes (KB -> bytes; FETCH_SIZE doubled: an upper estimate for this kernel's 8-byte-per-lane
+    entry loads, see profiles/traffic.json).  Returns (bytes per sweep, how) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 is not on PATH"
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sapca_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if not files:
+                return None, f"rocprofv3 --pmc {counter} left no counter file"
+            total = 0.0
+            for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if r["Counter_Name"] == counter and any(kname in r["Kernel_Name"] for kname in ("spmm_dq", "spmm_quad", "spmm_rowgather", "spmm_tiled")):
+                    total += float(r["Counter_Value"])
+            kb[counter] = total / n_sweeps
+        except Exception as e:
+            return None, f"rocprofv3 --pmc {counter}: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if kb["FETCH_SIZE"] <= 0:
+        return None, "no sweep kernel in the counter file"
+    return int(kb["FETCH_SIZE"] * 1024 * 2 + kb["WRITE_SIZE"] * 1024), (
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of one step of this workload as child processes; "
+        f"per sweep (the step's sweep-kernel counters / {n_sweeps} sweeps); KB x 1024, FETCH_SIZE doubled (gfx950: an upper estimate here)")
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -383,6 +424,7 @@ def main():
     ap.add_argument("--weak-c2", action="store_true",
                     help="N > 1: after the strong-scaled C4 headline also run 3 steps of weak-scaled C2 shards (a `weak_c2` record)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (use the committed figure)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="time the CPU restatement on the first ROWS rows of the workload instead of all of it (C2 whole: about a minute)")
     ap.add_argument("--no-extras", action="store_true",
@@ -451,14 +493,18 @@ def main():
             extra["secondary_error"] = repr(e)
 
     traffic, traffic_source = None, None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_traffic:
+        traffic, traffic_source = measure_traffic(args.workload, 2 * q + 3)      # 2q + 2 sweeps of the fit + the projection's
+        if traffic is None:
+            traffic_source = "not measured in this run (" + traffic_source + "); "
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if traffic is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath)).get(args.workload, {})
             traffic = tj.get("hbm_bytes_per_launch")
             if traffic is not None:
                 # not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (tools/pmc_traffic.sh)
-                traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command; not measured in this run)"
+                traffic_source = (traffic_source or "") + "profiles/traffic.json (committed rocprofv3 --pmc passes of this command; not measured in this run)"
         except Exception:
             traffic = None
     if rank == 0:

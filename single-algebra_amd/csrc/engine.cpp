@@ -79,6 +79,7 @@ void collect_timings(sapca_handle_s& h, bool is_fit) {
     t.lanczos_steps = keep_steps;
   } else {
     t.transform_ms = 0;
+    for (int ev : h.small_in_transform) t.transform_ms -= h.timer.ms(ev);   // the held-back small SVD counts as small_svd_ms only
   }
   double comm_dev_ms = 0;
   for (auto& sp : h.spans) {
@@ -991,6 +992,7 @@ void Engine<T>::finish_small_svd(H& h, const double** sign_out) {
   T* X = h.panel_x.ptr<T>();
   try {
     std::unique_ptr<Scope> sc(deferred ? new Scope(h, C_SMALL) : nullptr);   // (not deferred: inside fit_randomized's own span)
+    if (sc && sc->ev >= 0) h.small_in_transform.push_back(sc->ev);             // (it lies inside the projection's span: taken out of transform_ms)
     double* g = static_cast<double*>(h.small_host.p);
     double* M = g + (size_t)ld * ld;
     const int* info_pinned = reinterpret_cast<const int*>(M + (size_t)ld * ldk);
@@ -1064,6 +1066,7 @@ void Engine<T>::fit(H& h, const CsrView<T>& A, bool defer_finish) {
                     (h.comm.active() || (double)A.rows * lw * lw <= 400e3 * 64.0 * 64.0);
   }
   h.spans.clear();
+  h.small_in_transform.clear();
   h.comm.host_ms = 0;
   h.timer.begin_collect(s, h.opt.collect_timings != 0);
   const int total_ev = h.timer.start();

@@ -116,6 +116,7 @@ struct sapca_handle_s {
 
   sapca::EventTimer timer;
   std::vector<std::pair<int, int>> spans;  // (category, event index) of the last fit/transform
+  std::vector<int> small_in_transform;      // events of a held-back small SVD that ran inside the projection's span
   sapca_timings timings{};
   sapca::Comm comm;
 };

@@ -56,6 +56,17 @@ __host__ __device__ inline int dq_first(int wave, int nquads) { return wave * nq
 // first (profiles/r05_dq_stamps_c2.txt).
 __host__ __device__ inline int stream_of_wave(int hw_wave) { return (hw_wave & 3) * 4 + 3 - (hw_wave >> 2); }
 
+// Which (row block, tile range) a workgroup takes when the tile range of an operator is split over workgroups (A^T of a tall
+// matrix: few row blocks, each streaming the whole m x 64 panel).  Workgroups are dealt to the eight XCDs round-robin
+// (workgroup i runs on XCD i mod 8) and every XCD has its own L2: with (block, range) = (i / nsplit, i mod nsplit) the
+// workgroups that walk ONE tile range -- and could share its refills -- sit on eight different L2s, and at C5 (49 row blocks,
+// a 1 GB panel) 15.5 of the 25 GB of refills a pass requests leave the L2 (profiles/r05_c5_traffic.txt).  Here XCD x takes a
+// contiguous run of the list ordered by (tile range, row block): its 32 workgroups walk one or two tile ranges together.
+__device__ inline int xcd_run_index(int i, int total) {
+  const int x = i & 7, y = i >> 3, q = total >> 3, r = total & 7;
+  return x * q + min(x, r) + y;   // XCD x holds q workgroups, one more for x < total mod 8
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
@@ -106,7 +117,12 @@ spmm_dq_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restrict_
 #endif
                 ) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  if (nsplit > 1) {
+    const int nrb_here = (int)gridDim.x / nsplit, j = xcd_run_index((int)blockIdx.x, (int)gridDim.x);
+    sp = j / nrb_here;
+    rb = rb0 + j % nrb_here;
+  }
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
   const int wave = stream_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)), lane = threadIdx.x & (WAVE - 1);   // (the stream this wave walks)
   const int g = lane / 16, q = lane % 16;
@@ -229,7 +245,12 @@ spmm_dq_f64_kernel(const int32_t* __restrict__ blk_row0, const uint32_t* __restr
                    int ldx, int nsplit, int tiles_per_split, double* __restrict__ out, int64_t out_rows_total, int ldo, int ncols,
                    const double* __restrict__ cvec, int rb0) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  int rb = rb0 + blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  if (nsplit > 1) {
+    const int nrb_here = (int)gridDim.x / nsplit, j = xcd_run_index((int)blockIdx.x, (int)gridDim.x);
+    sp = j / nrb_here;
+    rb = rb0 + j % nrb_here;
+  }
   const int ct0 = sp * tiles_per_split, ct1 = min(nct, ct0 + tiles_per_split);
   const int wave = stream_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)), lane = threadIdx.x & (WAVE - 1);   // (the stream this wave walks)
   const int g = lane / 16, q = lane % 16;

@@ -1176,6 +1176,30 @@ def test_wide_panel_fit_transform_two_column_passes():
     np.testing.assert_allclose(res[1][1][:, :12], res[0][1][:, :12], atol=2e-3 * np.abs(res[0][1][:, :12]).max())
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_fit_transform_is_fit_followed_by_transform(variant):
+    """The reference's fit_transform IS fit() then transform() (sparse/mod.rs:355-358).  Here fit_transform of an unmasked f32
+    randomized fit projects with the un-rotated panel while the host solves the l x l problem (engine.cpp, finish_small_svd)
+    and a separate transform projects with the fitted components: one model, two routes, the same scores to f32 rounding
+    (the 2e-4 bound of PROJ_ATOL), and the stage timings count the held-back small SVD once."""
+    m, n, k, p, q = 30000, 2500, 12, 8, 3
+    ptr, idx, val = csr_np(synth.gapped_csr(m, n, 0.04, k, seed=29, dtype=torch.float32))
+    om = synth.gaussian_panel(n, k + p, 3).numpy()
+    x = mat(ptr, idx, val, m, n)
+    a = _builder(k, p, q).spmm_variant(variant).collect_timings(True).build().set_omega(om)
+    t_a = a.fit_transform(x)
+    tm = a.timings()
+    assert tm.transform_ms > 0 and tm.small_svd_ms > 0
+    b = _builder(k, p, q).spmm_variant(variant).build().set_omega(om)
+    b.fit(x)
+    t_b = b.transform(x)
+    np.testing.assert_allclose(a.singular_values_(np.float64), b.singular_values_(np.float64), rtol=1e-6)
+    np.testing.assert_allclose(a.components_(np.float64), b.components_(np.float64), atol=1e-6)
+    np.testing.assert_allclose(t_a, t_b, atol=2e-4 * np.abs(t_b).max())
+    t_c = a.transform(x)   # and the same handle projects the same way afterwards
+    np.testing.assert_allclose(t_c, t_b, atol=2e-4 * np.abs(t_b).max())
+
+
 def test_f64_wide_panel_fit_through_the_staged_sweep():
     """l = 100 in f64: two 64-column passes over 512-byte-row tiles, fit and projection (k = 90), against the oracle"""
     m, n, k, p, q = 3000, 400, 90, 10, 2
