@@ -169,12 +169,45 @@ def test_release_library_reads_no_experiment_switches():
     assert names == ["SAPCA_AT_OVERLAP", "SAPCA_MULTI_INPROCESS"], names
     assert len(sites) <= 8, sites
     rel = open(L.LIB_PATH, "rb").read()
-    for name in (b"SAPCA_TILED_FMT", b"SAPCA_AT_NATURAL", b"SAPCA_TRANSPOSE_GATHER", b"SAPCA_MASK_TRANSPOSE_FIRST", b"SAPCA_COMM_FORCE_RCCL"):
+    for name in (b"SAPCA_TILED_FMT", b"SAPCA_AT_NATURAL", b"SAPCA_TRANSPOSE_GATHER", b"SAPCA_MASK_TRANSPOSE_FIRST", b"SAPCA_COMM_FORCE_RCCL",
+                 b"SAPCA_RCCL_LIBRARY"):   # (the tests' stand-in for librccl is reachable from the debug build only)
         assert name not in rel, f"the release library carries the switch {name.decode()}"
     assert b"SAPCA_AT_OVERLAP" in rel
     if os.path.exists(L.DEBUG_LIB_PATH):
         dbg = open(L.DEBUG_LIB_PATH, "rb").read()
-        assert b"SAPCA_TILED_FMT" in dbg and b"SAPCA_COMM_FORCE_RCCL" in dbg
+        assert b"SAPCA_TILED_FMT" in dbg and b"SAPCA_COMM_FORCE_RCCL" in dbg and b"SAPCA_RCCL_LIBRARY" in dbg
         lib = L.load_debug()
         for name in L.EXPORTED_SYMBOLS:
             assert hasattr(lib, name), name
+
+
+def test_stand_in_librccl_is_test_infrastructure_only():
+    """tests/fake_rccl is reached through SAPCA_RCCL_LIBRARY by the debug build and by nothing else: no product source, build
+    file or Python module names it, and it exports exactly the entry points csrc/comm.cpp binds."""
+    import glob
+    prod = glob.glob(os.path.join(ROOT, "single-algebra_amd", "**", "*"), recursive=True) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for f in prod:
+        if os.path.isfile(f) and not f.endswith((".so", ".o")) and "/build" not in f:
+            txt = open(f, errors="replace").read()
+            assert "fake_rccl" not in txt or f.endswith(("comm.cpp", "switches.h")), f
+    src = open(os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.c")).read()
+    exported = set(re.findall(r'extern "C" __attribute__\(\(visibility\("default"\)\)\) [\w\s\*]+?\b(nccl\w+)\(', src))
+    bound = set(re.findall(r'dlsym\(a\.so, "(nccl\w+)"\)', open(os.path.join(ROOT, "single-algebra_amd", "csrc", "comm.cpp")).read()))
+    assert exported == bound and len(bound) == 8, (exported, bound)
+
+
+def test_bench_probes_for_the_reference_binary_and_says_why_not(monkeypatch):
+    """bench.py looks for cargo + a registry before any GPU call and reports the reference binary as
+    unavailable (with the reason) where they are missing -- as in this image."""
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    r = bench.reference_binary_baseline()
+    assert r["available"] is False and "cargo" in r["reason"]
+    got, why = bench.measure_traffic("c2", 11)      # no rocprofv3 on PATH (patched): the committed figure is used instead
+    assert got is None and "rocprofv3" in why
+    sweep, total = bench.alg_bytes(200_000, 20_000, 119_990_071, 60, 50, 4)
+    assert sweep == 119_990_071 * 8 + 200_001 * 8 + 20_000 * 60 * 4 + 200_000 * 60 * 4 == 1_014_320_576   # SURVEY.md 8d formula at C2
