@@ -93,29 +93,35 @@ void Comm::init_rccl(uint32_t nranks_, uint32_t rank_, const uint8_t id[128]) {
   rccl_comm.store(c);
   mode = RCCL;
   aborted.store(false);
-  // the side stream's communicator: a collective split with one colour (every rank enters it right behind the init)
+  // The side stream's communicator (a collective split with one colour) is only made where the two-piece A^T sweep is asked
+  // for (SAPCA_AT_OVERLAP=1: opt-in under RCCL, engine.cpp) -- and only if EVERY rank asks: ranks count the ones that do not
+  // with one all-reduce on the main communicator (a rank entering ncclCommSplit alone would wait for ever), split, and count
+  // the ranks whose split failed the same way; any of them drops the duplicate everywhere.
   rccl_comm2.store(nullptr);
-  ncclComm_t c2 = nullptr;
-  if (api().CommSplit && dbg_env("SAPCA_COMM_NO_SPLIT") == nullptr) {
-    if (api().CommSplit(c, 0, (int)rank, &c2, nullptr) != 0) c2 = nullptr;
-  }
-  // Every rank must see the same answer (a rank without the duplicate sweeps A^T in one piece and issues different
-  // collectives): one all-reduce on the main communicator counts the ranks whose split failed, and any failure drops the
-  // duplicate everywhere.  (Ranks whose library has no ncclCommSplit at all take part with "failed".)
   float* d_flag = nullptr;
   SAPCA_HIP(hipMalloc(&d_flag, sizeof(float)));
-  const float missing = c2 ? 0.f : 1.f;
-  float total = 1.f;
   int rc = 0;
-  hipError_t he = hipMemcpy(d_flag, &missing, sizeof(float), hipMemcpyHostToDevice);
-  if (he == hipSuccess) rc = api().AllReduce(d_flag, d_flag, 1, kNcclFloat32, kNcclSum, c, nullptr);
-  if (he == hipSuccess && rc == 0) he = hipStreamSynchronize(nullptr);
-  if (he == hipSuccess && rc == 0) he = hipMemcpy(&total, d_flag, sizeof(float), hipMemcpyDeviceToHost);
-  (void)hipFree(d_flag);
-  if (he != hipSuccess || rc != 0 || total != 0.f) {
-    if (c2 && api().CommDestroy) (void)api().CommDestroy(c2);
-    c2 = nullptr;
+  hipError_t he = hipSuccess;
+  const auto missing_anywhere = [&](bool mine_missing) {   // true when any rank says "missing" (or the exchange itself failed)
+    const float missing = mine_missing ? 1.f : 0.f;
+    float total = 1.f;
+    he = hipMemcpy(d_flag, &missing, sizeof(float), hipMemcpyHostToDevice);
+    if (he == hipSuccess) rc = api().AllReduce(d_flag, d_flag, 1, kNcclFloat32, kNcclSum, c, nullptr);
+    if (he == hipSuccess && rc == 0) he = hipStreamSynchronize(nullptr);
+    if (he == hipSuccess && rc == 0) he = hipMemcpy(&total, d_flag, sizeof(float), hipMemcpyDeviceToHost);
+    return he != hipSuccess || rc != 0 || total != 0.f;
+  };
+  const char* ov = getenv("SAPCA_AT_OVERLAP");
+  const bool want = ov != nullptr && atoi(ov) != 0 && api().CommSplit && dbg_env("SAPCA_COMM_NO_SPLIT") == nullptr;
+  ncclComm_t c2 = nullptr;
+  if (!missing_anywhere(!want)) {
+    if (api().CommSplit(c, 0, (int)rank, &c2, nullptr) != 0) c2 = nullptr;
+    if (missing_anywhere(c2 == nullptr)) {
+      if (c2 && api().CommDestroy) (void)api().CommDestroy(c2);
+      c2 = nullptr;
+    }
   }
+  (void)hipFree(d_flag);
   rccl_comm2.store(c2);
   check(rc, "ncclAllReduce (side-lane agreement)");
   SAPCA_HIP(he);

@@ -802,7 +802,8 @@ void Engine<T>::fit_randomized(H& h) {
       // cannot or will not sweep in pieces -- so that every rank's collectives have the same sizes.  The votes came with the
       // column statistics when every rank had its A^T format by then (no extra collective, no host round trip here);
       // otherwise one small all-reduce.
-      const bool mine = tiled && k::spmm_tiled_pieces_ok(h.tiled_at, 2, ld);
+      // (only A^T's format matters for the pieces -- the vote may have been cast before A's own format was known to be built)
+      const bool mine = h.tiled_at.valid && k::spmm_tiled_pieces_ok(h.tiled_at, 2, ld);
       if (h.vote_ready) {
         cut = h.vote_cut;
         SAPCA_CHECK(cut == 0 || mine, SAPCA_ERR_COMM, "internal: the ranks agreed on a two-piece A^T sweep this rank cannot run");

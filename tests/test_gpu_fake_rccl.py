@@ -93,7 +93,8 @@ def _worker_overlap(rank, world, port, tmpdir, fake):
                 os.environ["SAPCA_AT_OVERLAP"] = overlap
             est = make()
             _rccl_init(est, dist, L, world, rank)
-            assert est.comm_has_side_lane()             # the split gave every rank its duplicate
+            # the duplicate communicator of the side stream exists exactly where every rank asked for the two-piece sweep at init
+            assert est.comm_has_side_lane() == (overlap == "1")
             t = est.fit_transform(shard)
             tm = est.timings()
             assert int(tm.at_sweep_pieces) == (2 if overlap == "1" else 1), (overlap, int(tm.at_sweep_pieces))

@@ -57,7 +57,8 @@ PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from t
 # is 13 instructions instead of 15, with one conditional branch instead of two.
 ONEBR = os.environ.get("DQ2_ONEBR", "1") != "0"   # (the default since round 5; DQ2_ONEBR=0: a check per step)
 ROT = int(os.environ.get("DQ2_ROT", "2"))        # (the default since round 5: 2; DQ2_ROT=0: none)
-ROT_SHIFT = int(os.environ.get("DQ2_ROT_SHIFT", "1"))
+ROT_SHIFT = int(os.environ.get("DQ2_ROT_SHIFT", "1"))   # -1: per tile, 1 for streams of more than DQ2_ROT_LONG chunks, else 0 (short streams: a chunk is a big share of the tile)
+ROT_LONG = int(os.environ.get("DQ2_ROT_LONG", "7"))
 ROT_SUB = int(os.environ.get("DQ2_ROT_SUB", "0"))     # 2: min(3, max(0, remaining - SUB) >> SHIFT)
 ROT_AGE = os.environ.get("DQ2_ROT_AGE", "0") != "0"   # 2: the wave's place among its SIMD's four (0 = oldest) is added to `remaining`, and is
                                                       # its priority between the tile barrier and its first chunk (the youngest leaves the barrier last)
@@ -141,6 +142,7 @@ S_CTLA = [88, 90, 92]         # s[88:93] the three chunk routines
 S_BODY0 = 94                  # s[94:95] position 0 of slot 0's copy
 S_QM = 96                     # s[96:97] lanes that hold one of this wave's quads
 S_ROT = 83                    # DQ2_ROT=1: chunks started + the wave's place among the four of its SIMD
+S_SH = 67                     # DQ2_ROT_SHIFT=-1: this tile's shift of the remaining-chunks priority
 
 _uid = [0]
 
@@ -438,8 +440,10 @@ def chunk_routines(L, pattern):
                     L.append(f"s_add_u32 s{S_E}, s{S_E}, s{S_ROT}")
                 if ROT_SUB:
                     L += [f"s_max_u32 s{S_E}, s{S_E}, {ROT_SUB}", f"s_sub_u32 s{S_E}, s{S_E}, {ROT_SUB}"]
-                if ROT_SHIFT:
+                if ROT_SHIFT > 0:
                     L.append(f"s_lshr_b32 s{S_E}, s{S_E}, {ROT_SHIFT}")
+                elif ROT_SHIFT < 0:
+                    L.append(f"s_lshr_b32 s{S_E}, s{S_E}, s{S_SH}")
                 L.append(f"s_min_u32 s{S_E}, s{S_E}, 3")
             setprio_tree(L, S_E, f"c{r}")
         # one LDS-DMA piece of the next tile while there are any (out of line)
@@ -564,6 +568,8 @@ def body(pattern):
           f"s_add_u32 s{S_DLDS}, s{S_DLDS}, %[wdma]", f"s_mov_b32 s{S_NP}, 5"]
     dma_tile_setup(L)
     L += [f"v_add_u32 v{VLB}, s{S_BUF}, %[lb]", f"s_mov_b32 s{S_REM}, s{S_NCH}"]
+    if ROT == 2 and ROT_SHIFT < 0:
+        L += [f"s_cmp_gt_u32 s{S_NCH}, {ROT_LONG}", f"s_cselect_b32 s{S_SH}, 1, 0"]
     # the routine of chunk 0's entry buffer
     L += [f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[0]}:{S_CTLA[0] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 0", "s_cbranch_scc1 ctl_set",
           f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[1]}:{S_CTLA[1] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 ctl_set",
