@@ -55,6 +55,12 @@ PRIO = os.environ.get("DQ2_PRIO", "0") != "0"   # per-tile issue priority from t
 # One counter check per POSITION (two steps) instead of one per step: `s_sub 2` borrows exactly when the quad ends inside the
 # position (1 or 2 steps left), and that case runs out of line (end_s_k: once per quad and tile).  The straight path of a position
 # is 13 instructions instead of 15, with one conditional branch instead of two.
+# The tile barrier as late as it can be: everything between "my pieces have landed" and the first chunk that touches neither the
+# LDS tile nor the other buffer (the wait for the step counts, their four VALU instructions, the next tile's DMA set-up, the
+# chunk routine's choice) runs BEFORE s_barrier -- the waves that arrive early do it while they would wait anyway, and all sixteen
+# start streaming right behind the barrier instead of queueing 50 instructions each behind it (the youngest wave of a SIMD
+# entered its first chunk 550 cycles after the oldest: profiles/r05_dq_stamps_final.txt).
+LATEBAR = os.environ.get("DQ2_LATEBAR", "1") != "0"   # (the default since round 5)
 ONEBR = os.environ.get("DQ2_ONEBR", "1") != "0"   # (the default since round 5; DQ2_ONEBR=0: a check per step)
 ROT = int(os.environ.get("DQ2_ROT", "2"))        # (the default since round 5: 2; DQ2_ROT=0: none)
 ROT_SHIFT = int(os.environ.get("DQ2_ROT_SHIFT", "1"))   # -1: per tile, 1 for streams of more than DQ2_ROT_LONG chunks, else 0 (short streams: a chunk is a big share of the tile)
@@ -552,13 +558,16 @@ def body(pattern):
     # this wave's pieces of the tile have landed: wait for all but what was issued after the last of them
     stamp(L, ST_R + 1)
     wait_vmcnt(L, S_ND, 6)
-    stamp(L, ST_R + 2)
-    L += ["s_barrier"]
-    if ROT == 2 and ROT_AGE:
-        setprio_tree(L, S_ROT, "bar")
-    if ROT == 3:
-        L.append("s_setprio 3")
-    stamp(L, ST_R + 3)
+    def tile_barrier(L):
+        stamp(L, ST_R + 2)
+        L += ["s_barrier"]
+        if ROT == 2 and ROT_AGE:
+            setprio_tree(L, S_ROT, "bar")
+        if ROT == 3:
+            L.append("s_setprio 3")
+        stamp(L, ST_R + 3)
+    if not LATEBAR:
+        tile_barrier(L)
     # the step counts (issued before the last three entry loads of a linked predecessor); everything of a tile that loaded its own
     L += [f"s_cmp_lg_u32 s{S_PRE}, 0", "s_cbranch_scc1 cnt_pre", "s_waitcnt vmcnt(0)", "s_branch cnt_ok", "cnt_pre:", "s_waitcnt vmcnt(3)", "cnt_ok:"]
     L += [f"v_mov_b32 v{VCNT}, v{VCNT2}" if ODD else f"v_lshrrev_b32 v{VCNT}, 1, v{VCNT2}", f"v_add_u32 v{VCNT}, -1, v{VCNT}", f"s_mov_b64 vcc, s[{S_QM}:{S_QM + 1}]",
@@ -574,6 +583,8 @@ def body(pattern):
     L += [f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[0]}:{S_CTLA[0] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 0", "s_cbranch_scc1 ctl_set",
           f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[1]}:{S_CTLA[1] + 1}]", f"s_cmp_eq_u32 s{S_BASE}, 1", "s_cbranch_scc1 ctl_set",
           f"s_mov_b64 s[{S_CTL}:{S_CTL + 1}], s[{S_CTLA[2]}:{S_CTLA[2] + 1}]", "ctl_set:"]
+    if LATEBAR:
+        tile_barrier(L)
     stamp(L, ST_R + 4)
     if STAMPS:
         stamp_pairs_clear(L)
