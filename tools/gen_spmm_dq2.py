@@ -655,18 +655,33 @@ def main():
         out.write(f"#define DQ2_ACC_BASE {ACC}\n#define DQ2_TILE_BYTES {TILE_B}\n#define DQ2_ODD_STEPS {1 if ODD else 0}\n")
         if STAMPS:
             out.write("#define DQ2_STAMPS 1\n")
+        # the pattern variant (quirk Q3) differs from the plain one by three instructions in each chunk routine: one macro body with
+        # a parameter at those places instead of two copies of the loop
+        out.write('#define DQ2_PAT_LINES "s_nop 0\\n" "v_cmp_neq_f32 vcc, 0, v%d\\n" "v_cndmask_b32 v%d, 0, 1.0, vcc\\n"\n' % (ECUR[1], ECUR[1]))
         for rg in (8, 16):   # 512-row and 1024-row blocks
-            for pattern in (False, True):
-                RG = rg
-                set_depth_regs()
-                _uid[0] = 0
-                L = uniq_labels(body(pattern))
-                name = f"DQ2_MAIN_ASM_{rg}" + ("_PAT" if pattern else "")
-                out.write(f"#define {name} \\\n")
-                for ln in L:
-                    out.write(f'  "{ln}\\n" \\\n')
-                out.write("\n")
-                print(f"wrote {name}: {len(L)} lines")
+            RG = rg
+            set_depth_regs()
+            _uid[0] = 0
+            plain = uniq_labels(body(False))
+            _uid[0] = 0
+            pat = uniq_labels(body(True))
+            out.write(f"#define DQ2_MAIN_ASM_{rg}_(PAT) \\\n")
+            i = j = 0
+            marks = 0
+            while i < len(plain):
+                if plain[i] == pat[j]:
+                    out.write(f'  "{plain[i]}\\n" \\\n')
+                    i += 1
+                    j += 1
+                else:   # the pattern variant's three extra lines stand here
+                    assert pat[j] == "s_nop 0" and pat[j + 1].startswith("v_cmp_neq_f32") and pat[j + 2].startswith("v_cndmask_b32"), pat[j:j + 3]
+                    out.write("  PAT \\\n")
+                    j += 3
+                    marks += 1
+            assert j == len(pat) and marks == 3, (j, len(pat), marks)
+            out.write("\n")
+            out.write(f'#define DQ2_MAIN_ASM_{rg} DQ2_MAIN_ASM_{rg}_("")\n#define DQ2_MAIN_ASM_{rg}_PAT DQ2_MAIN_ASM_{rg}_(DQ2_PAT_LINES)\n')
+            print(f"wrote DQ2_MAIN_ASM_{rg}(_PAT): {len(plain)} lines")
             out.write(f"#define DQ2_MAIN_CLOBBERS_{rg} " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
         # the f64 sweep: four row slots per lane group (blocks of <= 256 rows, the f64 quad format's), accumulators from v80;
         # the f32 experiment switches (B64, FMAC, ILV, DEPTH, stamps) do not apply to it
