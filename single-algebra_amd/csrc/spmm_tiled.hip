@@ -1824,10 +1824,26 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
     atomicOr(&mask[slot * ATD_MASK_WORDS + (i >> 5)], 1u << (i & 31u));
   }
   __syncthreads();
+  // Set bits in the mask words before each word, per slot (round 5: a rank was up to ten LDS reads and popcounts; now two reads).
+  // The table takes the place of `row_of`, which nobody reads once the held entries are fetched; chunks too long to be held
+  // assemble their image there later and keep the loop over the words.
+  const bool held = b1 - b0 <= (int64_t)HOLD * ATD_THREADS;   // no entry is ranked again below: the masks' LDS joins the image
+  uint16_t* pre = reinterpret_cast<uint16_t*>(stage);        // [QBLOCK_ROWS][ATD_MASK_WORDS]
+  for (int slot = threadIdx.x; slot < QBLOCK_ROWS; slot += ATD_THREADS) {   // (and the entries of every row of the block in this tile)
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < ATD_MASK_WORDS; ++w) {
+      if (held) pre[slot * ATD_MASK_WORDS + w] = (uint16_t)run;
+      run += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
+    }
+    len_s[slot] = (uint16_t)run;
+  }
+  __syncthreads();
   // rank of an entry inside its (A^T row, tile) segment = the rows of the tile before its own that hold the column
   auto rank_of = [&](uint32_t slot, uint32_t i) {
     const uint32_t* mk = mask + slot * ATD_MASK_WORDS;
     uint32_t rank = __builtin_popcount(mk[i >> 5] & ((1u << (i & 31u)) - 1u));
+    if (held) return rank + (uint32_t)pre[slot * ATD_MASK_WORDS + (i >> 5)];
     for (uint32_t w = 0; w < (i >> 5); ++w) rank += __builtin_popcount(mk[w]);
     return rank;
   };
@@ -1842,15 +1858,9 @@ atd_fill_kernel(const uint2* __restrict__ bucket, const int64_t* __restrict__ bu
   // The image is two halves: while one run of quads is written out (and summed), the next is assembled in the other half --
   // one barrier per run.  Slots are written exactly once: entries by the threads that hold them, the padding behind a
   // row's last entry by a thread per row.
-  const bool held = b1 - b0 <= (int64_t)HOLD * ATD_THREADS;   // no entry is ranked again below: the masks' LDS joins the image
   const uint32_t HALF = held ? (uint32_t)(MASK_WORDS_ALL / 2 + ATD_STAGE_ENT) / 2u : (uint32_t)ATD_STAGE_ENT / 2u;   // (a quad holds at most 4 x 320 entries)
   Ent* const image = held ? reinterpret_cast<Ent*>(pool) : stage;
-  for (int slot = threadIdx.x; slot < QBLOCK_ROWS; slot += ATD_THREADS) {   // entries of every row of the block in this tile
-    int len = 0;
-    for (int w = 0; w < ATD_MASK_WORDS; ++w) len += __builtin_popcount(mask[slot * ATD_MASK_WORDS + w]);
-    len_s[slot] = (uint16_t)len;
-  }
-  __syncthreads();
+  __syncthreads();   // (every rank is known: the image may take the masks' and the table's LDS)
   auto row_len = [&](int slot) { return (int)len_s[slot]; };
   int half = 0;
   for (int q0 = 0; q0 < nquads; half ^= 1) {
