@@ -2295,7 +2295,13 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
   const int qf_cap_max = f32 ? QF_CAP_MAX : QF_CAP_MIN;
   const bool staged_fill = quad && !transposed && !rows_tile_major && dbg_env("SAPCA_FILL_DIRECT") == nullptr &&
                            (double)total <= 0.93 * qf_cap_max * ((double)op_rows / 4.0) && nct <= 768;   // (a quad above the image takes the direct route inside the kernel)
-  const int qf_cap = (double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max;
+  // The image is sized to the operator's average quad + 12 % (round 5; rounds 1-4: 4096 or 6144 entries): a workgroup's LDS is
+  // what limits the fill's residency (its waves sit out two memory round trips each), and C2's quads of 3 100 slots fit five
+  // workgroups per CU instead of four.  A quad above the image takes the direct route inside the kernel, as before.
+  static const bool qf_cap_fixed = dbg_env("SAPCA_QF_CAP_FIXED") != nullptr;
+  const double quad_avg = (double)total / std::max(1.0, (double)op_rows / 4.0);
+  const int qf_cap_fit = (int)std::min<int64_t>(qf_cap_max, std::max<int64_t>(2048, round_up((int64_t)(1.12 * quad_avg) + 64, 256)));
+  const int qf_cap = (!f32 || qf_cap_fixed) ? ((double)total <= 0.85 * QF_CAP_MIN * ((double)op_rows / 4.0) ? QF_CAP_MIN : qf_cap_max) : qf_cap_fit;
   const bool runs_fill = quad && !transposed && rows_tile_major && nct <= Q_MAX_TILES_RUNS;
   if ((packed_rows || direct) && !runs_fill) {
     if (aux_pending) SAPCA_HIP(hipStreamWaitEvent(s, buf.aux_join, 0));

@@ -15,7 +15,7 @@
 //                SAPCA_AT_SORT, SAPCA_PREPARE_SERIAL, SAPCA_PREPARE_ASIDE_FIRST, SAPCA_LANCZOS_TRANSPOSE, SAPCA_MASK_STATS_INLINE,
 //                SAPCA_MASK_SUMS_SCATTER, SAPCA_MASK_TRANSPOSE_FIRST, SAPCA_SMALL_SVD_QR, SAPCA_Q3_ROWKERNEL
 //   spmm_tiled.hip  SAPCA_DQ_BLOCK_ROWS, SAPCA_SPLIT_WGS, SAPCA_TILED_FMT, SAPCA_TILED_SLOTS, SAPCA_TILED_MODE, SAPCA_TILED_GEOM128,
-//                SAPCA_TILE_DEFAULT, SAPCA_NO_ROWSORT, SAPCA_ROWSORT_ALWAYS, SAPCA_FILL_DIRECT, SAPCA_AT_BUCKETS, SAPCA_AT_SORT,
+//                SAPCA_TILE_DEFAULT, SAPCA_QF_CAP_FIXED, SAPCA_NO_ROWSORT, SAPCA_ROWSORT_ALWAYS, SAPCA_FILL_DIRECT, SAPCA_AT_BUCKETS, SAPCA_AT_SORT,
 //                SAPCA_RUNS_SEG_LDS_MAX, SAPCA_SWEEP_STAGED, SAPCA_NO_DQ, SAPCA_DEBUG
 //   spmm_dq.hip  SAPCA_NO_DQ, SAPCA_NO_DQ_F64      spmm.hip  SAPCA_ROWGATHER_PER_ENTRY      prep.hip  SAPCA_TRANSPOSE_GATHER
 //   dense.hip    SAPCA_CHOL_GENERAL, SAPCA_EIG_DEVICE
