@@ -1506,7 +1506,9 @@ constexpr int ATD_HIST_THREADS_WIDE = 1024;   // histograms above 64 KiB leave o
 // row's indices for the histogram anyway.
 __global__ void __launch_bounds__(ATD_HIST_THREADS_WIDE)
 atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t m, int nct, int tc, int64_t n2,
-                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, uint32_t* __restrict__ bnd, int64_t* __restrict__ disorder) {
+                uint16_t* __restrict__ cnt16, float blk_scale, int nrb, uint32_t* __restrict__ bnd, int64_t* __restrict__ disorder,
+                unsigned long long* __restrict__ slots_to_clear) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && slots_to_clear) *slots_to_clear = 0ull;   // (atd_rowlen_kernel, next on this stream, adds to it)
   // disorder: set when a row's entries leave the order the run ends rely on (a block after a later block: the caller handed
   // over rows whose columns do not ascend) -- the host then takes the bucket route, which maps every column through a table
   extern __shared__ uint32_t atd_h32[];   // n2 / 2 words: counters of columns 2w, 2w + 1
@@ -1572,7 +1574,8 @@ atd_hist_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx
 // len[c] = entries of column c (summed over the tiles); the caller scans it into A^T's row offsets.
 // A workgroup takes 64 columns, its 16 waves a sixteenth of the tiles each.
 __global__ void __launch_bounds__(1024)
-atd_rowlen_kernel(const uint16_t* __restrict__ cnt16, int64_t n, int64_t n2, int nct, int64_t* __restrict__ len) {
+atd_rowlen_kernel(const uint16_t* __restrict__ cnt16, int64_t n, int64_t n2, int nct, int64_t* __restrict__ len,
+                  unsigned long long* __restrict__ natural_slots) {
   __shared__ uint32_t part[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
@@ -1593,11 +1596,21 @@ atd_rowlen_kernel(const uint16_t* __restrict__ cnt16, int64_t n, int64_t n2, int
   }
   part[grp][lane] = a;
   __syncthreads();
-  if (grp == 0 && c <= n) {
+  if (grp == 0) {
     int64_t total = 0;
     if (c < n)
       for (int g = 0; g < 16; ++g) total += part[g][lane];
-    len[c] = total;   // (len[n] = 0: the scan turns it into the total)
+    if (c <= n) len[c] = total;   // (len[n] = 0: the scan turns it into the total)
+    // what the quads would hold if A^T's rows kept their natural order: 4 x the longest of every four consecutive rows
+    // (natural_quad_slots_kernel's sum, gathered here: the builder then needs neither that kernel nor the memset in front of it)
+    if (natural_slots) {
+      int64_t mx = max(total, __shfl_xor(total, 1));
+      mx = max(mx, __shfl_xor(mx, 2));
+      unsigned long long acc = (lane & 3) == 0 ? (unsigned long long)(4 * mx) : 0ull;
+#pragma unroll
+      for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == 0 && acc) atomicAdd(natural_slots, acc);
+    }
   }
 }
 
@@ -1986,6 +1999,7 @@ struct AtDirectSrc {
   const uint32_t* bnd;     // gather fill: ends of every (A^T row block, A row) run for `nrb_nat` natural blocks (or null)
   int64_t nrb_nat;
   const std::vector<int32_t>* blk_nat;   // ... and where those blocks start (float_blocks below)
+  bool slots_done = false;               // buf.misc holds the natural quads' slot count already (atd_rowlen_kernel)
 };
 
 // The natural blocks of the gather fill: block_of(c) = (int)((float)c * scale), with the scale taken down from nrb / n until
@@ -2131,8 +2145,10 @@ bool build_tiled_t(const CsrView<VT>& S, bool transposed, int ldp_elems, TiledOp
     // natural order is assumed until then (one wait for the device instead of two); a matrix that needs the sort
     // pays for a second round of counting.
     unsigned long long* d_slots = reinterpret_cast<unsigned long long*>(buf.misc.as<int64_t>(8)) + 4;
-    SAPCA_HIP(hipMemsetAsync(d_slots, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(natural_quad_slots_kernel, dim3(grid_for((S.rows + 3) / 4, 256, 1024)), dim3(256), 0, s, S.ptr, S.rows, d_slots);
+    if (!(direct && direct->slots_done)) {
+      SAPCA_HIP(hipMemsetAsync(d_slots, 0, sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(natural_quad_slots_kernel, dim3(grid_for((S.rows + 3) / 4, 256, 1024)), dim3(256), 0, s, S.ptr, S.rows, d_slots);
+    }
     SAPCA_HIP(hipMemcpyAsync(pinned, d_slots, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     speculate = true;
     sort_rows = false;
@@ -2449,15 +2465,16 @@ bool build_tiled_at_direct(const CsrView<float>& A, int ldp, TiledOp& op, TiledB
   float blk_scale = 0.f;
   if (bnd) float_blocks(n, nrb_nat, blk_nat, blk_scale);
   int64_t* d_disorder = buf.misc.as<int64_t>(8) + 6;   // (read back with the builder's one host exchange)
+  unsigned long long* d_slots = reinterpret_cast<unsigned long long*>(buf.misc.as<int64_t>(8)) + 4;   // (the natural quads' slots: build_tiled_t reads them back)
   SAPCA_HIP(hipMemsetAsync(d_disorder, 0, sizeof(int64_t), s));
   hipLaunchKernelGGL(atd_hist_kernel, dim3((unsigned)nct), dim3((size_t)n2 * 2 > 52 * 1024 ? ATD_HIST_THREADS_WIDE : ATD_HIST_THREADS),   // (above 52 KiB two workgroups share a CU: sixteen waves each)
-                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, blk_scale, (int)nrb_nat, bnd, d_disorder);
-  hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr);
+                     hist_lds, s, A.ptr, A.idx, m, nct, tc, n2, cnt16, blk_scale, (int)nrb_nat, bnd, d_disorder, d_slots);
+  hipLaunchKernelGGL(atd_rowlen_kernel, dim3((unsigned)((n + 64) / 64)), dim3(1024), 0, s, cnt16, n, n2, nct, at_ptr, d_slots);
   launch_small_scan(at_ptr, nullptr, n, nullptr, s);
   SAPCA_HIP(hipGetLastError());
   CsrView<float> At;
   At.rows = n; At.cols = m; At.nnz = A.nnz; At.ptr = at_ptr; At.idx = nullptr; At.val = nullptr;
-  AtDirectSrc src{&A, cnt16, n2, &scratch, stats, bnd, nrb_nat, &blk_nat};
+  AtDirectSrc src{&A, cnt16, n2, &scratch, stats, bnd, nrb_nat, &blk_nat, true};
   return build_tiled_t<float>(At, false, ldp, op, buf, s, true, nullptr, true, false, &src);
 }
 
