@@ -1200,6 +1200,35 @@ def test_fit_transform_is_fit_followed_by_transform(variant):
     np.testing.assert_allclose(t_c, t_b, atol=2e-4 * np.abs(t_b).max())
 
 
+def test_dpp_fed_sweep_on_random_shapes_against_the_row_kernel():
+    """Both products, centred and not, of 30 random operators -- ragged rows, a run of empty rows, one row that holds every
+    column, 1 to 128 panel columns, blocks of a few quads -- through the DPP-fed sweep (forced) against the row kernel: the
+    generated main loop's corner cases (a quad of one step, a stream that ends inside a position, a wave without quads,
+    a tile range split over workgroups) with numbers behind them.  tools/fuzz_sweep.py runs more of the same."""
+    rng = np.random.default_rng(11)
+    dq, row = ops.Session(spmm_variant=2), ops.Session(spmm_variant=1)
+    for case in range(30):
+        m, n = int(rng.integers(1, 5000)), int(rng.integers(1, 4000))
+        l = int(rng.choice([1, 3, 16, 30, 60, 64, 65, 100, 128]))
+        A = sp.random(m, n, density=float(rng.choice([0.002, 0.01, 0.05, 0.2])), format="csr", dtype=np.float32,
+                      random_state=int(rng.integers(1 << 30)))
+        if case % 2 and m > 8:
+            r = rng.choice(m, size=3, replace=False)
+            A = (A + sp.csr_matrix((np.full(n, 0.5, np.float32), (np.full(n, r[0]), np.arange(n))), shape=(m, n))).tolil()
+            A[r[1], :] = 0
+            A[r[2], :] = 0
+            A = A.tocsr()
+            A.eliminate_zeros()
+        A.sort_indices()
+        for transposed in (False, True):
+            X = rng.standard_normal(((m if transposed else n), l)).astype(np.float32)
+            mu = rng.standard_normal(n).astype(np.float32) if case % 3 else None
+            a = dq.spmm(A.indptr, A.indices, A.data, m, n, X, mu, transposed)
+            b = row.spmm(A.indptr, A.indices, A.data, m, n, X, mu, transposed)
+            assert np.isfinite(a).all()
+            np.testing.assert_allclose(a, b, atol=2e-5 * max(1e-30, float(np.abs(b).max())), err_msg=f"case {case} m {m} n {n} l {l} T {transposed}")
+
+
 def test_f64_wide_panel_fit_through_the_staged_sweep():
     """l = 100 in f64: two 64-column passes over 512-byte-row tiles, fit and projection (k = 90), against the oracle"""
     m, n, k, p, q = 3000, 400, 90, 10, 2
